@@ -1,0 +1,96 @@
+"""ctypes binding of csrc/libgtgvae_hip.so (declared in include/gtgvae.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+caller gets an exception.  Build with ``make -C gtg-vae_amd/csrc`` (or
+``python -c "import __graft_entry__ as g; g.build()"``).
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgtgvae_hip.so")
+
+_lib = None
+
+
+class GtgError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_SIGS = {
+    "gtg_version": (c_int, []),
+    "gtg_last_error": (ctypes.c_char_p, []),
+    "gtg_max_nodes": (c_int, []),
+    "gtg_mst_batched_triu": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
+    "gtg_mst_batched_full": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
+    "gtg_edge_prf": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P]),
+    "gtg_adj_build": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, _P]),
+    "gtg_encoder_fwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "gtg_encoder_fwd": (c_int, [_P] * 6 + [c_int64, c_int, c_int, c_int] + [_P] * 3 + [_P, c_size_t, _P]),
+    "gtg_encoder_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "gtg_encoder_bwd": (c_int, [_P] * 7 + [c_int64, c_int, c_int, c_int] + [_P] * 4 + [_P, c_size_t, _P]),
+    "gtg_latent_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "gtg_latent_fwd": (c_int, [_P] * 6 + [c_int64, c_int] + [_P] * 4 + [_P, c_size_t, _P]),
+    "gtg_latent_bwd": (c_int, [_P] * 7 + [c_float, _P, c_int64, c_int] + [_P] * 5 + [_P, c_size_t, _P]),
+    "gtg_reparam_kl_fwd": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P, c_size_t, _P]),
+    "gtg_reparam_kl_bwd": (c_int, [_P, _P, _P, _P, c_float, _P, c_int64, c_int, _P, _P, _P]),
+    "gtg_decoder_fwd": (c_int, [_P] * 5 + [c_int64, c_int, c_int, c_int] + [_P, _P, _P]),
+    "gtg_bce_workspace_bytes": (c_size_t, [c_int64]),
+    "gtg_bce_loss_fwd": (c_int, [_P, _P, c_int64, c_int, _P, _P, c_size_t, _P]),
+    "gtg_bce_loss_bwd": (c_int, [_P, _P, c_float, _P, c_int64, c_int, c_int, _P, _P]),
+    "gtg_decoder_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "gtg_decoder_bwd": (c_int, [_P] * 7 + [c_int, c_float, _P, c_int64, c_int, c_int, c_int] + [_P] * 5 + [_P, c_size_t, _P]),
+    "gtg_adam_step": (c_int, [_P] * 4 + [c_int64, _P, c_float, c_float, c_float, c_float, c_float, _P]),
+    "gtg_gemm_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, c_int, _P, c_int, _P, c_size_t, _P]),
+    "gtg_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """The loaded library; raises GtgError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GtgError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(make -C gtg-vae_amd/csrc); there is no fallback path"
+            )
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().gtg_last_error().decode(errors="replace")
+        raise GtgError(f"{what or 'gtg call'} failed with code {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GtgError(
+                "gtg_vae_amd runs on the GPU only (tensor on %s); move the module and its inputs to 'cuda'" % t.device
+            )

@@ -1,0 +1,541 @@
+// extern "C" boundary of libgtgvae_hip.so (declared in include/gtgvae.h).
+//
+// Rules of the boundary: plain pointers and sizes only; every buffer
+// (inputs, outputs, workspaces) is owned and allocated by the caller as device
+// memory; nothing here allocates, frees or synchronises; every kernel is
+// launched on the caller's stream, so a whole training step can be captured
+// into a HIP graph.  Return value 0 = OK, negative = error, message via
+// gtg_last_error().
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gtgvae.h"
+#include "gtg_internal.h"
+
+namespace gtg {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GTG_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return GTG_OK;
+}
+
+namespace {
+
+// Bump carver over a caller-provided workspace.  With base == nullptr it only
+// measures, so the *_workspace_bytes entry points and the real calls share one
+// layout.
+struct Carver {
+    char* base;
+    size_t cap;
+    size_t off = 0;
+    bool overflow = false;
+    Carver(void* b, size_t c) : base(reinterpret_cast<char*>(b)), cap(c) {}
+    template <typename T>
+    T* take(size_t count)
+    {
+        const size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+        const size_t at = off;
+        off += bytes;
+        if (base == nullptr) return nullptr;
+        if (off > cap) {
+            overflow = true;
+            return nullptr;
+        }
+        return reinterpret_cast<T*>(base + at);
+    }
+};
+
+inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
+}  // namespace
+}  // namespace gtg
+
+using namespace gtg;
+
+#define GTG_REQUIRE(cond, msg) \
+    do {                       \
+        if (!(cond)) return set_error(GTG_ERR_INVALID, "%s: %s", __func__, msg); \
+    } while (0)
+#define GTG_TRY(expr)           \
+    do {                        \
+        const int _rc = (expr); \
+        if (_rc != GTG_OK) return _rc; \
+    } while (0)
+
+extern "C" {
+
+int gtg_version(void) { return GTG_VERSION; }
+
+const char* gtg_last_error(void) { return g_err; }
+
+int gtg_max_nodes(void) { return 64; }
+
+// ---------------------------------------------------------------------------
+// MST read-out and edge statistics
+// ---------------------------------------------------------------------------
+int gtg_mst_batched_triu(const float* rows, int64_t num_graphs, int n, int32_t* edges, int32_t* count, void* stream)
+{
+    return mst_triu(rows, num_graphs, n, edges, count, (hipStream_t)stream);
+}
+
+int gtg_mst_batched_full(const float* mats, int64_t num_graphs, int n, int32_t* edges, int32_t* count, void* stream)
+{
+    return mst_full(mats, num_graphs, n, edges, count, (hipStream_t)stream);
+}
+
+int gtg_edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gold_bits, int64_t num_graphs, int n,
+                 float* recall, float* precision, void* stream)
+{
+    GTG_REQUIRE(n >= 0 && n <= 64 && num_graphs >= 0, "bad size");
+    GTG_REQUIRE(num_graphs == 0 || (edges && count && gold_bits && recall && precision), "null pointer");
+    return edge_prf(edges, count, gold_bits, num_graphs, n, recall, precision, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// normalised adjacency from the ragged edge list
+// ---------------------------------------------------------------------------
+int gtg_adj_build(const int64_t* edge_index, int64_t num_edges, int64_t num_graphs, int n, int32_t* counts_ws,
+                  int32_t* err_flag, float* adj, void* stream)
+{
+    GTG_REQUIRE(num_edges >= 0 && num_graphs >= 0, "negative size");
+    GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
+    if (num_graphs == 0) return GTG_OK;
+    GTG_REQUIRE(counts_ws && err_flag && adj && (num_edges == 0 || edge_index), "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    GTG_TRY(adj_count(edge_index, num_edges, num_graphs, n, counts_ws, err_flag, s));
+    return adj_normalize(counts_ws, num_graphs, n, adj, s);
+}
+
+// ---------------------------------------------------------------------------
+// encoder: two GCN layers + max-pool over all n rows of each graph
+// ---------------------------------------------------------------------------
+static void enc_fwd_layout(Carver& c, int64_t B, int n, int d, bool has_x, float** xw1, float** t2)
+{
+    const size_t rows = (size_t)B * n;
+    *xw1 = has_x ? c.take<float>(rows * 2 * d) : nullptr;
+    *t2 = c.take<float>(rows * d);
+}
+
+size_t gtg_encoder_fwd_workspace_bytes(int64_t num_graphs, int n, int f, int d, int has_x)
+{
+    (void)f;
+    Carver c(nullptr, 0);
+    float *a, *b;
+    enc_fwd_layout(c, num_graphs, n, d, has_x != 0, &a, &b);
+    return c.off;
+}
+
+int gtg_encoder_fwd(const float* adj, const float* x, const float* W1, const float* b1, const float* W2,
+                    const float* b2, int64_t num_graphs, int n, int f, int d, float* h1, float* pooled,
+                    int32_t* argmax, void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 0 && f >= 1 && d >= 1, "bad size");
+    GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
+    GTG_REQUIRE(x != nullptr || f == n, "identity node features need input_dim == n");
+    if (num_graphs == 0) return GTG_OK;
+    GTG_REQUIRE(adj && W1 && b1 && W2 && b2 && h1 && pooled && argmax, "null pointer");
+    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4, "batch too large");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)num_graphs, H = 2 * d, rows = B * n;
+    Carver c(ws, ws_bytes);
+    float *xw1, *t2;
+    enc_fwd_layout(c, B, n, d, x != nullptr, &xw1, &t2);
+    if (c.overflow || (c.off > 0 && ws == nullptr)) return set_error(GTG_ERR_WORKSPACE, "gtg_encoder_fwd: workspace too small");
+
+    GemmDesc g;
+    if (x) {
+        // XW1 = X * W1^T
+        g = GemmDesc();
+        g.A = x; g.lda = f; g.a_kc = true;
+        g.B = W1; g.ldb = f; g.b_kc = true;
+        g.C = xw1; g.ldc = H;
+        g.M = rows; g.N = H; g.K = f;
+        GTG_TRY(gemm(g, s));
+        // H1[b] = relu(A_b * XW1[b] + b1)
+        g = GemmDesc();
+        g.A = adj; g.lda = n; g.a_kc = true; g.strideA = (long long)n * n;
+        g.B = xw1; g.ldb = H; g.b_kc = false; g.strideB = (long long)n * H;
+        g.C = h1; g.ldc = H; g.strideC = (long long)n * H;
+        g.M = n; g.N = H; g.K = n; g.batch = B;
+        g.bias = b1; g.epi = EPI_RELU;
+        GTG_TRY(gemm(g, s));
+    } else {
+        // X = I_n per graph: XW1[b] = W1^T, so H1[b] = relu(A_b * W1^T + b1)
+        g = GemmDesc();
+        g.A = adj; g.lda = n; g.a_kc = true; g.strideA = (long long)n * n;
+        g.B = W1; g.ldb = f; g.b_kc = true; g.strideB = 0;
+        g.C = h1; g.ldc = H; g.strideC = (long long)n * H;
+        g.M = n; g.N = H; g.K = n; g.batch = B;
+        g.bias = b1; g.epi = EPI_RELU;
+        GTG_TRY(gemm(g, s));
+    }
+    // T2 = H1 * W2^T
+    g = GemmDesc();
+    g.A = h1; g.lda = H; g.a_kc = true;
+    g.B = W2; g.ldb = H; g.b_kc = true;
+    g.C = t2; g.ldc = d;
+    g.M = rows; g.N = d; g.K = H;
+    GTG_TRY(gemm(g, s));
+    // pooled[b] = max_rows(A_b * T2[b] + b2)
+    g = GemmDesc();
+    g.A = adj; g.lda = n; g.a_kc = true; g.strideA = (long long)n * n;
+    g.B = t2; g.ldb = d; g.b_kc = false; g.strideB = (long long)n * d;
+    g.M = n; g.N = d; g.K = n; g.batch = B;
+    g.bias = b2; g.epi = EPI_POOL; g.pool_val = pooled; g.pool_idx = argmax;
+    return gemm(g, s);
+}
+
+struct EncBwdWs {
+    float *dT2, *dZ1, *dXW1, *cs, *slabs;
+};
+
+static void enc_bwd_layout(Carver& c, int64_t B, int n, int f, int d, bool has_x, EncBwdWs* w)
+{
+    const size_t rows = (size_t)B * n;
+    const int H = 2 * d;
+    w->dT2 = c.take<float>(rows * d);
+    w->dZ1 = c.take<float>(rows * H);
+    w->dXW1 = has_x ? c.take<float>(rows * H) : nullptr;
+    const size_t cs = max2(colsum_workspace(B, d), colsum_workspace((int64_t)rows, H));
+    w->cs = reinterpret_cast<float*>(c.take<char>(cs));
+    const size_t sl = max2(gemm_splitk_workspace(d, H, (int)rows, 1), gemm_splitk_workspace(H, f, (int)rows, 1));
+    w->slabs = reinterpret_cast<float*>(c.take<char>(sl));
+}
+
+size_t gtg_encoder_bwd_workspace_bytes(int64_t num_graphs, int n, int f, int d, int has_x)
+{
+    Carver c(nullptr, 0);
+    EncBwdWs w;
+    enc_bwd_layout(c, num_graphs, n, f, d, has_x != 0, &w);
+    return c.off;
+}
+
+int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const float* W2, const float* h1,
+                    const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int f, int d, float* dW1,
+                    float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, void* stream)
+{
+    (void)W1;
+    GTG_REQUIRE(num_graphs >= 1 && f >= 1 && d >= 1, "bad size");
+    GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
+    GTG_REQUIRE(x != nullptr || f == n, "identity node features need input_dim == n");
+    GTG_REQUIRE(adj && W2 && h1 && argmax && dpooled && dW1 && db1 && dW2 && db2, "null pointer");
+    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4, "batch too large");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)num_graphs, H = 2 * d, rows = B * n;
+    Carver c(ws, ws_bytes);
+    EncBwdWs w;
+    enc_bwd_layout(c, B, n, f, d, x != nullptr, &w);
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_encoder_bwd: workspace too small");
+
+    // max-pool routing through the second propagate, and db2
+    GTG_TRY(pool_bwd_gather(adj, dpooled, argmax, B, n, d, w.dT2, s));
+    GTG_TRY(colsum(dpooled, B, d, d, w.cs, db2, s));
+    GemmDesc g;
+    // dW2 = dT2^T * H1
+    g = GemmDesc();
+    g.A = w.dT2; g.lda = d; g.a_kc = false;
+    g.B = h1; g.ldb = H; g.b_kc = false;
+    g.C = dW2; g.ldc = H;
+    g.M = d; g.N = H; g.K = rows;
+    g.splits = gemm_pick_splits(d, H, rows, 1); g.slabs = w.slabs;
+    GTG_TRY(gemm(g, s));
+    // dZ1 = (dT2 * W2) masked by relu
+    g = GemmDesc();
+    g.A = w.dT2; g.lda = d; g.a_kc = true;
+    g.B = W2; g.ldb = H; g.b_kc = false;
+    g.C = w.dZ1; g.ldc = H;
+    g.M = rows; g.N = H; g.K = d;
+    g.epi = EPI_MASK; g.aux = h1; g.ldaux = H;
+    GTG_TRY(gemm(g, s));
+    GTG_TRY(colsum(w.dZ1, rows, H, H, w.cs, db1, s));
+    if (x) {
+        // dXW1[b] = A_b^T * dZ1[b]
+        g = GemmDesc();
+        g.A = adj; g.lda = n; g.a_kc = false; g.strideA = (long long)n * n;
+        g.B = w.dZ1; g.ldb = H; g.b_kc = false; g.strideB = (long long)n * H;
+        g.C = w.dXW1; g.ldc = H; g.strideC = (long long)n * H;
+        g.M = n; g.N = H; g.K = n; g.batch = B;
+        GTG_TRY(gemm(g, s));
+        // dW1 = dXW1^T * X
+        g = GemmDesc();
+        g.A = w.dXW1; g.lda = H; g.a_kc = false;
+        g.B = x; g.ldb = f; g.b_kc = false;
+        g.C = dW1; g.ldc = f;
+        g.M = H; g.N = f; g.K = rows;
+        g.splits = gemm_pick_splits(H, f, rows, 1); g.slabs = w.slabs;
+        return gemm(g, s);
+    }
+    // X = I_n: dW1[c][i] = sum_{b,j} dZ1[b,j,c] * A[b,j,i]
+    g = GemmDesc();
+    g.A = w.dZ1; g.lda = H; g.a_kc = false;
+    g.B = adj; g.ldb = n; g.b_kc = false;
+    g.C = dW1; g.ldc = f;
+    g.M = H; g.N = n; g.K = rows;
+    g.splits = gemm_pick_splits(H, n, rows, 1); g.slabs = w.slabs;
+    return gemm(g, s);
+}
+
+// ---------------------------------------------------------------------------
+// latent head: mu / logvar linears, reparameterisation with supplied eps, KL
+// ---------------------------------------------------------------------------
+size_t gtg_latent_workspace_bytes(int64_t num_graphs, int d)
+{
+    Carver c(nullptr, 0);
+    c.take<float>((size_t)((num_graphs * d + 255) / 256) + 1);          // KL block partials
+    c.take<float>((size_t)num_graphs * d);                               // dmu
+    c.take<float>((size_t)num_graphs * d);                               // dlogvar
+    c.take<char>(colsum_workspace(num_graphs, d));
+    c.take<char>(gemm_splitk_workspace(d, d, (int)num_graphs, 1));
+    return c.off;
+}
+
+int gtg_latent_fwd(const float* h, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
+                   const float* eps, int64_t num_graphs, int d, float* mu, float* logvar, float* z, float* kl,
+                   void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
+    GTG_REQUIRE(h && Wmu && bmu && Wlv && blv && eps && mu && logvar && z && kl, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)num_graphs;
+    Carver c(ws, ws_bytes);
+    float* partial = c.take<float>((size_t)((num_graphs * d + 255) / 256) + 1);
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_latent_fwd: workspace too small");
+    GemmDesc g;
+    g.A = h; g.lda = d; g.B = Wmu; g.ldb = d; g.C = mu; g.ldc = d;
+    g.M = B; g.N = d; g.K = d; g.bias = bmu;
+    GTG_TRY(gemm(g, s));
+    g.B = Wlv; g.C = logvar; g.bias = blv;
+    GTG_TRY(gemm(g, s));
+    return reparam_kl(mu, logvar, eps, B, d, z, partial, kl, s);
+}
+
+int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const float* mu, const float* logvar,
+                   const float* eps, const float* dz, float kl_w, const float* kl_w_dev, int64_t num_graphs, int d,
+                   float* dWmu, float* dbmu, float* dWlv, float* dblv, float* dh, void* ws, size_t ws_bytes,
+                   void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
+    GTG_REQUIRE(h && Wmu && Wlv && mu && logvar && eps && dWmu && dbmu && dWlv && dblv && dh, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)num_graphs;
+    Carver c(ws, ws_bytes);
+    c.take<float>((size_t)((num_graphs * d + 255) / 256) + 1);
+    float* dmu = c.take<float>((size_t)B * d);
+    float* dlv = c.take<float>((size_t)B * d);
+    float* cs = reinterpret_cast<float*>(c.take<char>(colsum_workspace(B, d)));
+    float* slabs = reinterpret_cast<float*>(c.take<char>(gemm_splitk_workspace(d, d, B, 1)));
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_latent_bwd: workspace too small");
+
+    GTG_TRY(latent_bwd_elem(dz, mu, logvar, eps, kl_w_dev, kl_w, B, d, dmu, dlv, s));
+    const int splits = gemm_pick_splits(d, d, B, 1);
+    GemmDesc g;
+    // dW = dY^T * h
+    g.A = dmu; g.lda = d; g.a_kc = false;
+    g.B = h; g.ldb = d; g.b_kc = false;
+    g.C = dWmu; g.ldc = d; g.M = d; g.N = d; g.K = B;
+    g.splits = splits; g.slabs = slabs;
+    GTG_TRY(gemm(g, s));
+    g.A = dlv; g.C = dWlv;
+    GTG_TRY(gemm(g, s));
+    GTG_TRY(colsum(dmu, B, d, d, cs, dbmu, s));
+    GTG_TRY(colsum(dlv, B, d, d, cs, dblv, s));
+    // dh = dmu * Wmu + dlogvar * Wlv
+    g = GemmDesc();
+    g.A = dmu; g.lda = d; g.a_kc = true;
+    g.B = Wmu; g.ldb = d; g.b_kc = false;
+    g.C = dh; g.ldc = d; g.M = B; g.N = d; g.K = d;
+    GTG_TRY(gemm(g, s));
+    g.A = dlv; g.B = Wlv; g.epi = EPI_ACCUM;
+    return gemm(g, s);
+}
+
+// Stand-alone reparameterisation + KL (GTVAE.reparameterize / GTVAE.loss_kl as
+// separate calls).  Workspace: gtg_latent_workspace_bytes.
+int gtg_reparam_kl_fwd(const float* mu, const float* logvar, const float* eps, int64_t num_graphs, int d, float* z,
+                       float* kl, void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
+    GTG_REQUIRE(mu && logvar && eps && z && kl, "null pointer");
+    Carver c(ws, ws_bytes);
+    float* partial = c.take<float>((size_t)((num_graphs * d + 255) / 256) + 1);
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_reparam_kl_fwd: workspace too small");
+    return reparam_kl(mu, logvar, eps, num_graphs, d, z, partial, kl, (hipStream_t)stream);
+}
+
+int gtg_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, const float* dz, float kl_w,
+                       const float* kl_w_dev, int64_t num_graphs, int d, float* dmu, float* dlogvar, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
+    GTG_REQUIRE(mu && logvar && eps && dmu && dlogvar, "null pointer");
+    return latent_bwd_elem(dz, mu, logvar, eps, kl_w_dev, kl_w, num_graphs, d, dmu, dlogvar, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// MLP edge decoder + un-masked upper-triangular BCE
+// ---------------------------------------------------------------------------
+int gtg_decoder_fwd(const float* z, const float* D1, const float* c1, const float* D2, const float* c2,
+                    int64_t num_graphs, int d, int hid, int m_out, float* y1, float* out, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && d >= 1 && hid >= 1 && m_out >= 1, "bad size");
+    GTG_REQUIRE(z && D1 && c1 && D2 && c2 && y1 && out, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)num_graphs;
+    GemmDesc g;
+    g.A = z; g.lda = d; g.B = D1; g.ldb = d; g.C = y1; g.ldc = hid;
+    g.M = B; g.N = hid; g.K = d; g.bias = c1; g.epi = EPI_RELU;
+    GTG_TRY(gemm(g, s));
+    g = GemmDesc();
+    g.A = y1; g.lda = hid; g.B = D2; g.ldb = hid; g.C = out; g.ldc = m_out;
+    g.M = B; g.N = m_out; g.K = hid; g.bias = c2; g.epi = EPI_SIGMOID;
+    return gemm(g, s);
+}
+
+size_t gtg_bce_workspace_bytes(int64_t num_graphs)
+{
+    Carver c(nullptr, 0);
+    c.take<float>((size_t)num_graphs + 1);
+    return c.off;
+}
+
+int gtg_bce_loss_fwd(const float* out, const float* adj_target, int64_t num_graphs, int n, float* loss, void* ws,
+                     size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && n >= 1, "bad size");
+    GTG_REQUIRE(out && adj_target && loss, "null pointer");
+    Carver c(ws, ws_bytes);
+    float* partial = c.take<float>((size_t)num_graphs + 1);
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_bce_loss_fwd: workspace too small");
+    return bce_fwd(out, adj_target, num_graphs, n, partial, loss, (hipStream_t)stream);
+}
+
+int gtg_bce_loss_bwd(const float* out, const float* adj_target, float gscale, const float* gscale_dev,
+                     int64_t num_graphs, int n, int through_sigmoid, float* grad, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && n >= 1, "bad size");
+    GTG_REQUIRE(out && adj_target && grad, "null pointer");
+    return bce_bwd(out, adj_target, num_graphs, n, gscale_dev, gscale, through_sigmoid, grad, (hipStream_t)stream);
+}
+
+struct DecBwdWs {
+    float *dy2, *dy1, *cs, *slabs;
+};
+
+static void dec_bwd_layout(Carver& c, int64_t B, int d, int hid, int m_out, DecBwdWs* w)
+{
+    w->dy2 = c.take<float>((size_t)B * m_out);
+    w->dy1 = c.take<float>((size_t)B * hid);
+    w->cs = reinterpret_cast<float*>(c.take<char>(max2(colsum_workspace(B, m_out), colsum_workspace(B, hid))));
+    w->slabs = reinterpret_cast<float*>(
+        c.take<char>(max2(gemm_splitk_workspace(m_out, hid, (int)B, 1), gemm_splitk_workspace(hid, d, (int)B, 1))));
+}
+
+size_t gtg_decoder_bwd_workspace_bytes(int64_t num_graphs, int d, int hid, int m_out)
+{
+    Carver c(nullptr, 0);
+    DecBwdWs w;
+    dec_bwd_layout(c, num_graphs, d, hid, m_out, &w);
+    return c.off;
+}
+
+// Exactly one of (dout) and (adj_target) is given:
+//   dout        gradient w.r.t. the decoder's sigmoid output (generic autograd path)
+//   adj_target  fuse the BCE backward: dy2 is produced straight from out/targets
+int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const float* y1, const float* out,
+                    const float* dout, const float* adj_target, int n, float gscale, const float* gscale_dev,
+                    int64_t num_graphs, int d, int hid, int m_out, float* dD1, float* dc1, float* dD2, float* dc2,
+                    float* dz, void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && d >= 1 && hid >= 1 && m_out >= 1, "bad size");
+    GTG_REQUIRE(z && D1 && D2 && y1 && out && dD1 && dc1 && dD2 && dc2 && dz, "null pointer");
+    GTG_REQUIRE((dout != nullptr) != (adj_target != nullptr), "give exactly one of dout / adj_target");
+    GTG_REQUIRE(adj_target == nullptr || m_out == n * (n + 1) / 2, "m_out must be n(n+1)/2 with fused BCE");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)num_graphs;
+    Carver c(ws, ws_bytes);
+    DecBwdWs w;
+    dec_bwd_layout(c, B, d, hid, m_out, &w);
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_decoder_bwd: workspace too small");
+
+    if (adj_target)
+        GTG_TRY(bce_bwd(out, adj_target, B, n, gscale_dev, gscale, 1, w.dy2, s));
+    else
+        GTG_TRY(sigmoid_bwd(out, dout, (int64_t)B * m_out, w.dy2, s));
+    GemmDesc g;
+    // dD2 = dy2^T * y1
+    g.A = w.dy2; g.lda = m_out; g.a_kc = false;
+    g.B = y1; g.ldb = hid; g.b_kc = false;
+    g.C = dD2; g.ldc = hid; g.M = m_out; g.N = hid; g.K = B;
+    g.splits = gemm_pick_splits(m_out, hid, B, 1); g.slabs = w.slabs;
+    GTG_TRY(gemm(g, s));
+    GTG_TRY(colsum(w.dy2, B, m_out, m_out, w.cs, dc2, s));
+    // dy1 = (dy2 * D2) masked by relu
+    g = GemmDesc();
+    g.A = w.dy2; g.lda = m_out; g.a_kc = true;
+    g.B = D2; g.ldb = hid; g.b_kc = false;
+    g.C = w.dy1; g.ldc = hid; g.M = B; g.N = hid; g.K = m_out;
+    g.epi = EPI_MASK; g.aux = y1; g.ldaux = hid;
+    GTG_TRY(gemm(g, s));
+    // dD1 = dy1^T * z
+    g = GemmDesc();
+    g.A = w.dy1; g.lda = hid; g.a_kc = false;
+    g.B = z; g.ldb = d; g.b_kc = false;
+    g.C = dD1; g.ldc = d; g.M = hid; g.N = d; g.K = B;
+    g.splits = gemm_pick_splits(hid, d, B, 1); g.slabs = w.slabs;
+    GTG_TRY(gemm(g, s));
+    GTG_TRY(colsum(w.dy1, B, hid, hid, w.cs, dc1, s));
+    // dz = dy1 * D1
+    g = GemmDesc();
+    g.A = w.dy1; g.lda = hid; g.a_kc = true;
+    g.B = D1; g.ldb = d; g.b_kc = false;
+    g.C = dz; g.ldc = d; g.M = B; g.N = d; g.K = hid;
+    return gemm(g, s);
+}
+
+// ---------------------------------------------------------------------------
+// optimiser
+// ---------------------------------------------------------------------------
+int gtg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, void* state16,
+                  float lr, float beta1, float beta2, float eps, float grad_scale, void* stream)
+{
+    GTG_REQUIRE(numel >= 0, "negative size");
+    GTG_REQUIRE(state16 && (numel == 0 || (param && grad && exp_avg && exp_avg_sq)), "null pointer");
+    return adam_stateful(param, grad, exp_avg, exp_avg_sq, numel, state16, lr, beta1, beta2, eps, grad_scale,
+                         (hipStream_t)stream);
+}
+
+// Plain GEMM entry (tests, and callers that want one of the three layouts).
+int gtg_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
+                 int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, void* slabs,
+                 size_t slab_bytes, void* stream)
+{
+    GTG_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_ACCUM, "unsupported epilogue");
+    GemmDesc g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.a_kc = a_kc != 0; g.b_kc = b_kc != 0; g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux;
+    if (slabs && !bias && (epilogue == EPI_STORE || epilogue == EPI_ACCUM)) {
+        const int sp = gemm_pick_splits(M, N, K, 1);
+        if (sp > 1 && (size_t)sp * M * N * sizeof(float) <= slab_bytes) {
+            g.splits = sp;
+            g.slabs = reinterpret_cast<float*>(slabs);
+        }
+    }
+    return gemm(g, (hipStream_t)stream);
+}
+
+size_t gtg_gemm_splitk_workspace_bytes(int M, int N, int K) { return gemm_splitk_workspace(M, N, K, 1); }
+
+}  // extern "C"

@@ -1,0 +1,444 @@
+// fp32-in / fp32-accumulate GEMM on the gfx950 matrix cores
+// (v_mfma_f32_32x32x2_f32), LDS-tiled, register-staged double buffering.
+//
+// One kernel template serves every dense contraction of the graph-VAE step:
+//   NT  C = A * W^T        activations x Linear / GCN weights (both K-contiguous)
+//   NN  C = A * B          dY * W (input gradients), A_hat (x) T (block-diagonal
+//                          normalised adjacency times node features, batched)
+//   TN  C = A^T * B        weight gradients (reduction over B*N rows, split-K)
+// Tiles are 64-lane-wavefront shaped: every wave owns TM x TN sub-tiles of
+// 32x32 whose accumulators live in 16 registers each; operand fragments are
+// one float per lane per MFMA (lane l: row l&31, k-slot l>>5).
+//
+// k order inside an 8-wide k group is permuted (lane half h, step s -> k = 4h+s)
+// so that K-contiguous tiles are read from LDS with one 16-byte ds_read_b128
+// per 4 MFMAs; A and B use the same permutation, so the product is unchanged.
+#include "gtg_internal.h"
+
+namespace gtg {
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct KArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* aux;
+    float* pool_val;
+    int32_t* pool_idx;
+    long long strideA, strideB, strideC, strideAux;
+    int M, N, K;
+    int lda, ldb, ldc, ldaux;
+    int tiles_m, tiles_n, splits, k_per_split;
+    int epi;
+    int vecA, vecB;
+    int to_slabs;  // write raw partials to C viewed as [batch*splits][M][N]
+};
+
+// Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).
+// Give each XCD a contiguous run of tile ids so that the tiles that re-read
+// one operand panel sit behind one L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, rem = nwg & 7;
+    const int xcd = bid & 7, within = bid >> 3;
+    const int base = (xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    return base + within;
+}
+
+// One operand tile: ROWS (the M or N extent) x BK.
+//   KC  : K contiguous in memory; LDS image [ROWS][BK+4]
+//   !KC : ROWS contiguous in memory; LDS image [BK][ROWS+4]
+// The +4 float pad keeps 16-byte alignment and makes both the ds_write_b128
+// of staging and the ds_read_b128 / ds_read_b32 of the fragment reads
+// bank-conflict-free.
+template <int ROWS, bool KC>
+struct Tile {
+    static constexpr int LD = KC ? (BK + 4) : (ROWS + 4);
+    static constexpr int SIZE = KC ? ROWS * LD : BK * LD;
+    static constexpr int NV = ROWS * BK / 4 / NTHREADS;
+    static constexpr int V4 = ROWS / 4;
+
+    __device__ static __forceinline__ void fetch(f32x4 (&reg)[NV], const float* __restrict__ base, int ld, int row0,
+                                                 int rows_total, int k0, int k_end, bool vec, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NTHREADS;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (KC) {
+                const int row = idx >> 3, c4 = idx & 7;
+                const int gr = row0 + row, gk = k0 + c4 * 4;
+                if (gr < rows_total && gk < k_end) {
+                    const float* p = base + (long long)gr * ld + gk;
+                    if (vec && gk + 3 < k_end) {
+                        v = *reinterpret_cast<const f32x4*>(p);
+                    } else {
+                        v[0] = p[0];
+                        if (gk + 1 < k_end) v[1] = p[1];
+                        if (gk + 2 < k_end) v[2] = p[2];
+                        if (gk + 3 < k_end) v[3] = p[3];
+                    }
+                }
+            } else {
+                const int kk = idx / V4, c4 = idx % V4;
+                const int gk = k0 + kk, gr = row0 + c4 * 4;
+                if (gk < k_end && gr < rows_total) {
+                    const float* p = base + (long long)gk * ld + gr;
+                    if (vec && gr + 3 < rows_total) {
+                        v = *reinterpret_cast<const f32x4*>(p);
+                    } else {
+                        v[0] = p[0];
+                        if (gr + 1 < rows_total) v[1] = p[1];
+                        if (gr + 2 < rows_total) v[2] = p[2];
+                        if (gr + 3 < rows_total) v[3] = p[3];
+                    }
+                }
+            }
+            reg[i] = v;
+        }
+    }
+
+    __device__ static __forceinline__ void stage(float* s, const f32x4 (&reg)[NV], int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NTHREADS;
+            if (KC) {
+                const int row = idx >> 3, c4 = idx & 7;
+                *reinterpret_cast<f32x4*>(&s[row * LD + c4 * 4]) = reg[i];
+            } else {
+                const int kk = idx / V4, c4 = idx % V4;
+                *reinterpret_cast<f32x4*>(&s[kk * LD + c4 * 4]) = reg[i];
+            }
+        }
+    }
+
+    // The 4 k values (k = 8g + 4h + s, s = 0..3) of row rbase + r.
+    __device__ static __forceinline__ f32x4 frag(const float* s, int rbase, int g, int r, int h)
+    {
+        if (KC) {
+            return *reinterpret_cast<const f32x4*>(&s[(rbase + r) * LD + 8 * g + 4 * h]);
+        } else {
+            const float* p = &s[(8 * g + 4 * h) * LD + rbase + r];
+            f32x4 v = {p[0], p[LD], p[2 * LD], p[3 * LD]};
+            return v;
+        }
+    }
+};
+
+template <int BM, int BN, int WAVES_M, bool AKC, bool BKC>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
+{
+    using TA = Tile<BM, AKC>;
+    using TB = Tile<BN, BKC>;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::SIZE + TB::SIZE)];
+    float* const sA0 = smem;
+    float* const sB0 = smem + TA::SIZE;
+    float* const sA1 = smem + TA::SIZE + TB::SIZE;
+    float* const sB1 = sA1 + TA::SIZE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = (wave / WAVES_N) * WTM, wn = (wave % WAVES_N) * WTN;
+
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % a.tiles_n;
+    bid /= a.tiles_n;
+    const int tm = bid % a.tiles_m;
+    bid /= a.tiles_m;
+    const int split = bid % a.splits;
+    const int batch = bid / a.splits;
+
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int k_begin = split * a.k_per_split;
+    const int k_end = min(a.K, k_begin + a.k_per_split);
+    const float* __restrict__ A = a.A + batch * a.strideA;
+    const float* __restrict__ B = a.B + batch * a.strideB;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[TA::NV], rb[TB::NV];
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    if (nk > 0) {
+        TA::fetch(ra, A, a.lda, m0, a.M, k_begin, k_end, a.vecA, tid);
+        TB::fetch(rb, B, a.ldb, n0, a.N, k_begin, k_end, a.vecB, tid);
+        TA::stage(sA0, ra, tid);
+        TB::stage(sB0, rb, tid);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* cA = (kt & 1) ? sA1 : sA0;
+        const float* cB = (kt & 1) ? sB1 : sB0;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int k0 = k_begin + (kt + 1) * BK;
+            TA::fetch(ra, A, a.lda, m0, a.M, k0, k_end, a.vecA, tid);
+            TB::fetch(rb, B, a.ldb, n0, a.N, k0, k_end, a.vecB, tid);
+        }
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = TA::frag(cA, wm + 32 * i, g, r, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = TB::frag(cB, wn + 32 * j, g, r, h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            TA::stage((kt & 1) ? sA0 : sA1, ra, tid);
+            TB::stage((kt & 1) ? sB0 : sB1, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  Accumulator register e of lane (r,h) is element
+    // (row = (e&3) + 8*(e>>2) + 4h, col = r) of its 32x32 tile.
+    if (a.epi == EPI_POOL) {
+        if (WAVES_M == 1) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn + 32 * j + r;
+                const float bias = (a.bias != nullptr && col < a.N) ? a.bias[col] : 0.f;
+                float best = 0.f;
+                int bi = -1;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float v = acc[i][j][e] + bias;
+                        if (row < a.M && (bi < 0 || v > best)) {
+                            best = v;
+                            bi = row;
+                        }
+                    }
+                const float ob = __shfl_xor(best, 32);
+                const int oi = __shfl_xor(bi, 32);
+                if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi < bi))) {
+                    best = ob;
+                    bi = oi;
+                }
+                if (h == 0 && col < a.N) {
+                    a.pool_val[(long long)batch * a.N + col] = best;
+                    a.pool_idx[(long long)batch * a.N + col] = bi;
+                }
+            }
+        }
+        return;
+    }
+
+    float* __restrict__ C;
+    int ldc;
+    if (a.to_slabs) {
+        C = a.C + ((long long)batch * a.splits + split) * (long long)a.M * a.N;
+        ldc = a.N;
+    } else {
+        C = a.C + batch * a.strideC;
+        ldc = a.ldc;
+    }
+    const float* __restrict__ aux = a.aux ? a.aux + batch * a.strideAux : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn + 32 * j + r;
+        if (col >= a.N) continue;
+        const float bias = (a.bias != nullptr && !a.to_slabs) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= a.M) continue;
+                float v = acc[i][j][e];
+                float* dst = C + (long long)row * ldc + col;
+                if (a.to_slabs) {
+                    *dst = v;
+                    continue;
+                }
+                v += bias;
+                switch (a.epi) {
+                    case EPI_RELU: v = fmaxf(v, 0.f); break;
+                    case EPI_SIGMOID: v = 1.f / (1.f + expf(-v)); break;
+                    case EPI_MASK: v = (aux[(long long)row * a.ldaux + col] > 0.f) ? v : 0.f; break;
+                    case EPI_ACCUM: v += *dst; break;
+                    default: break;
+                }
+                *dst = v;
+            }
+    }
+}
+
+// C (+)= sum over slabs, in slab order.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long mn,
+                                                            int N, float* __restrict__ C, int ldc, int accumulate)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mn) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slabs[(long long)k * mn + i];
+    const long long row = i / N, col = i % N;
+    float* dst = C + row * ldc + col;
+    *dst = accumulate ? (*dst + s) : s;
+}
+
+enum TileCfg { CFG_128, CFG_64x128, CFG_64 };
+
+inline TileCfg pick_cfg(int M, int N, int batch, int epi)
+{
+    if (epi == EPI_POOL) return CFG_64x128;
+    if (batch > 1 && M <= 64) return CFG_64x128;
+    const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (t128 >= 192) return CFG_128;
+    return CFG_64;
+}
+
+inline void cfg_dims(TileCfg c, int& bm, int& bn)
+{
+    switch (c) {
+        case CFG_128: bm = 128; bn = 128; break;
+        case CFG_64x128: bm = 64; bn = 128; break;
+        default: bm = 64; bn = 64; break;
+    }
+}
+
+template <int BM, int BN, int WAVES_M>
+int launch_cfg(const KArgs& k, bool akc, bool bkc, int grid, hipStream_t s)
+{
+    if (akc && bkc)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, true, true>), dim3(grid), dim3(NTHREADS), 0, s, k);
+    else if (akc && !bkc)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, true, false>), dim3(grid), dim3(NTHREADS), 0, s, k);
+    else if (!akc && !bkc)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, false, false>), dim3(grid), dim3(NTHREADS), 0, s, k);
+    else
+        return set_error(GTG_ERR_UNSUPPORTED, "gemm: A M-contiguous with B K-contiguous is not instantiated");
+    return check_launch("gemm_kernel");
+}
+
+}  // namespace
+
+int gemm_pick_splits(int M, int N, int K, int batch)
+{
+    if (batch != 1) return 1;
+    int bm, bn;
+    cfg_dims(pick_cfg(M, N, batch, EPI_STORE), bm, bn);
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    if (tiles >= 256 || K < 1024) return 1;
+    long long want = (768 + tiles - 1) / tiles;
+    const long long maxs = K / 256;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    int kps = (int)((K + want - 1) / want);
+    kps = (kps + BK - 1) / BK * BK;
+    return (K + kps - 1) / kps;
+}
+
+size_t gemm_splitk_workspace(int M, int N, int K, int batch)
+{
+    const int s = gemm_pick_splits(M, N, K, batch);
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+int gemm(const GemmDesc& d, hipStream_t s)
+{
+    if (d.M < 0 || d.N < 0 || d.K < 0 || d.batch < 0) return set_error(GTG_ERR_INVALID, "gemm: negative dimension");
+    if (d.M == 0 || d.N == 0 || d.batch == 0) return GTG_OK;
+    if (!d.A || !d.B) return set_error(GTG_ERR_INVALID, "gemm: null operand");
+    if (d.epi == EPI_POOL) {
+        if (d.M > 64 || !d.pool_val || !d.pool_idx)
+            return set_error(GTG_ERR_INVALID, "gemm: pooled epilogue needs M <= 64 and pool outputs");
+    } else if (!d.C) {
+        return set_error(GTG_ERR_INVALID, "gemm: null output");
+    }
+    if (d.epi == EPI_MASK && !d.aux) return set_error(GTG_ERR_INVALID, "gemm: mask epilogue without aux");
+
+    const TileCfg cfg = pick_cfg(d.M, d.N, d.batch, d.epi);
+    int bm, bn;
+    cfg_dims(cfg, bm, bn);
+
+    KArgs k;
+    k.A = d.A;
+    k.B = d.B;
+    k.C = d.C;
+    k.bias = d.bias;
+    k.aux = d.aux;
+    k.pool_val = d.pool_val;
+    k.pool_idx = d.pool_idx;
+    k.strideA = d.strideA;
+    k.strideB = d.strideB;
+    k.strideC = d.strideC;
+    k.strideAux = d.strideAux;
+    k.M = d.M;
+    k.N = d.N;
+    k.K = d.K;
+    k.lda = d.lda;
+    k.ldb = d.ldb;
+    k.ldc = d.ldc;
+    k.ldaux = d.ldaux;
+    k.tiles_m = (d.M + bm - 1) / bm;
+    k.tiles_n = (d.N + bn - 1) / bn;
+    k.epi = d.epi;
+    k.vecA = ((reinterpret_cast<uintptr_t>(d.A) & 15) == 0) && (d.lda % 4 == 0) && (d.strideA % 4 == 0);
+    k.vecB = ((reinterpret_cast<uintptr_t>(d.B) & 15) == 0) && (d.ldb % 4 == 0) && (d.strideB % 4 == 0);
+
+    int splits = 1;
+    if (d.splits > 1) {
+        if (d.batch != 1 || !d.slabs || (d.epi != EPI_STORE && d.epi != EPI_ACCUM) || d.bias)
+            return set_error(GTG_ERR_INVALID, "gemm: split-K needs batch 1, a slab workspace and a plain epilogue");
+        splits = d.splits;
+    }
+    int kps = (d.K + splits - 1) / splits;
+    kps = (kps + BK - 1) / BK * BK;
+    if (kps == 0) kps = BK;
+    splits = d.K > 0 ? (d.K + kps - 1) / kps : 1;
+    if (splits > 1 && splits > d.splits) return set_error(GTG_ERR_INVALID, "gemm: split count grew past the workspace");
+    k.splits = splits;
+    k.k_per_split = kps;
+    k.to_slabs = splits > 1 ? 1 : 0;
+    if (k.to_slabs) k.C = d.slabs;
+
+    const long long grid = (long long)k.tiles_m * k.tiles_n * splits * d.batch;
+    if (grid > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "gemm: grid too large");
+
+    int rc;
+    switch (cfg) {
+        case CFG_128: rc = launch_cfg<128, 128, 2>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        case CFG_64x128: rc = launch_cfg<64, 128, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        default: rc = launch_cfg<64, 64, 2>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+    }
+    if (rc != GTG_OK) return rc;
+    if (splits > 1) {
+        const long long mn = (long long)d.M * d.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, d.slabs, splits, mn,
+                           d.N, d.C, d.ldc, d.epi == EPI_ACCUM ? 1 : 0);
+        return check_launch("splitk_reduce_kernel");
+    }
+    return GTG_OK;
+}
+
+}  // namespace gtg

@@ -1,0 +1,461 @@
+// HBM-bound kernels of the graph-VAE step: adjacency build from the ragged
+// edge list, max-pool backward routing, column sums for bias gradients, the
+// reparameterisation + KL block, the un-masked upper-triangular BCE and its
+// backward, fused Adam, and edge precision/recall.
+//
+// Every reduction here is ordered (per-block tree in LDS, then a fixed-order
+// pass over the partials): the same inputs give bit-identical outputs, and no
+// float atomics are used.
+#include "gtg_internal.h"
+
+namespace gtg {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Sum over a 256-thread block; result valid in thread 0.
+__device__ __forceinline__ float block_sum_256(float v, float* sm /* >= 4 floats */)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// adjacency: counts[b][i][j] = #edges (src=j -> dst=i), self loops dropped.
+// Integer atomics: order-independent, exact.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adj_count_kernel(const int64_t* __restrict__ ei, int64_t E, int64_t B, int n,
+                                                        int32_t* __restrict__ counts, int32_t* __restrict__ err)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t s = ei[e], t = ei[E + e];
+    if (s == t) return;
+    const int64_t total = B * n;
+    if (s < 0 || t < 0 || s >= total || t >= total || s / n != t / n) {
+        atomicOr(err, 1);  // edge leaves its graph: not a block-diagonal batch
+        return;
+    }
+    const int64_t g = t / n;
+    atomicAdd(&counts[g * n * n + (t % n) * n + (s % n)], 1);
+}
+
+// One wave per graph (n <= 64): deg_i = 1 + sum_j counts[i][j];
+// adj[i][j] = deg_i^-1/2 * (counts[i][j] + [i==j]) * deg_j^-1/2.
+__global__ __launch_bounds__(64) void adj_normalize_kernel(const int32_t* __restrict__ counts, int n,
+                                                           float* __restrict__ adj)
+{
+    __shared__ float dis[64];
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int32_t* c = counts + b * n * n;
+    float* a = adj + b * n * n;
+    int deg = 1;
+    if (lane < n)
+        for (int j = 0; j < n; ++j) deg += c[lane * n + j];
+    dis[lane] = (lane < n) ? 1.0f / sqrtf((float)deg) : 0.f;
+    __syncthreads();
+    if (lane < n) {
+        const float dj = dis[lane];
+        for (int i = 0; i < n; ++i) {
+            const float w = (float)(c[i * n + lane] + (i == lane ? 1 : 0));
+            a[i * n + lane] = (dis[i] * w) * dj;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// max-pool backward routed through the second propagate:
+// dT2[b,j,c] = adj[b, argmax[b,c], j] * dpool[b,c]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_bwd_gather_kernel(const float* __restrict__ adj,
+                                                              const float* __restrict__ dpool,
+                                                              const int32_t* __restrict__ argmax, int n, int d,
+                                                              float* __restrict__ dT2)
+{
+    const int64_t b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const float g = dpool[b * d + c];
+    const int am = argmax[b * d + c];
+    const float* arow = adj + b * n * n + (int64_t)am * n;
+    float* out = dT2 + b * n * d + c;
+    for (int j = 0; j < n; ++j) out[(int64_t)j * d] = arow[j] * g;
+}
+
+// ---------------------------------------------------------------------------
+// column sums (bias gradients): two ordered stages.
+// ---------------------------------------------------------------------------
+constexpr int CS_COLS = 64;   // columns per block
+constexpr int CS_RG = 4;      // row lanes per block
+__host__ __device__ inline int cs_chunk_rows(int64_t rows)
+{
+    int64_t c = (rows + 255) / 256;
+    if (c < 64) c = 64;
+    return (int)c;
+}
+
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, int64_t rows, int cols, int ld,
+                                                     int chunk, float* __restrict__ partial)
+{
+    __shared__ float sm[CS_RG][CS_COLS];
+    const int cl = threadIdx.x % CS_COLS, rg = threadIdx.x / CS_COLS;
+    const int col = blockIdx.x * CS_COLS + cl;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk;
+    const int64_t r1 = min(rows, r0 + chunk);
+    float s = 0.f;
+    if (col < cols)
+        for (int64_t r = r0 + rg; r < r1; r += CS_RG) s += X[r * ld + col];
+    sm[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && col < cols)
+        partial[(int64_t)blockIdx.y * cols + col] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, int nchunks, int cols,
+                                                     float* __restrict__ out)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + col];
+    out[col] = s;
+}
+
+// ---------------------------------------------------------------------------
+// z = eps * exp(0.5 logvar) + mu ;  KL = -0.5 * sum(1 + logvar - mu^2 - e^logvar) / B
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reparam_kl_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                         const float* __restrict__ eps, int64_t total,
+                                                         float* __restrict__ z, float* __restrict__ partial)
+{
+    __shared__ float sm[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float term = 0.f;
+    if (i < total) {
+        const float m = mu[i], l = lv[i];
+        z[i] = eps[i] * expf(0.5f * l) + m;
+        term = 1.f + l - m * m - expf(l);
+    }
+    const float s = block_sum_256(term, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// out[0] = scale * sum(partial[0..n)), summed by one block in a fixed order.
+__global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ partial, int64_t n, float scale,
+                                                        float* __restrict__ out)
+{
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += partial[i];
+    const float t = block_sum_256(s, sm);
+    if (threadIdx.x == 0) out[0] = t * scale;
+}
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mu,
+                                                         const float* __restrict__ lv, const float* __restrict__ eps,
+                                                         const float* __restrict__ kl_w_dev, float kl_w, float inv_b,
+                                                         int64_t total, float* __restrict__ dmu,
+                                                         float* __restrict__ dlv)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float w = (kl_w_dev ? kl_w_dev[0] * kl_w : kl_w) * inv_b;
+    const float m = mu[i], l = lv[i], g = dz ? dz[i] : 0.f;
+    dmu[i] = g + w * m;
+    dlv[i] = g * (0.5f * eps[i] * expf(0.5f * l)) + w * 0.5f * (expf(l) - 1.f);
+}
+
+// ---------------------------------------------------------------------------
+// un-masked BCE over the padded upper triangle (diagonal included).
+// Element k = i*n - i(i-1)/2 + (j-i), i <= j, of row b of `out` pairs with
+// adj[b,i,j].  log terms clamp at -100 (binary_cross_entropy semantics).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ out, const float* __restrict__ adj,
+                                                      int n, int m, float* __restrict__ row_partial)
+{
+    __shared__ float sm[4];
+    const int64_t b = blockIdx.x;
+    const float* o = out + b * m;
+    const float* a = adj + b * n * n;
+    float s = 0.f;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx - i * n;
+        if (j < i) continue;
+        const int k = i * n - (i * (i - 1)) / 2 + (j - i);
+        const float p = o[k], t = a[idx];
+        const float lp = fmaxf(logf(p), -100.f);
+        const float lq = fmaxf(logf(1.f - p), -100.f);
+        s += (t - 1.f) * lq - t * lp;
+    }
+    const float tot = block_sum_256(s, sm);
+    if (threadIdx.x == 0) row_partial[b] = tot;
+}
+
+// dy2 = [g (p - t) / max((1-p) p, 1e-12)] * (1-p) p : BCE backward followed by
+// the sigmoid's backward, in the order autograd applies them.
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ out, const float* __restrict__ adj,
+                                                      int n, int m, const float* __restrict__ gdev, float g,
+                                                      int through_sigmoid, float* __restrict__ dy2)
+{
+    const int64_t b = blockIdx.x;
+    const float* o = out + b * m;
+    const float* a = adj + b * n * n;
+    float* d = dy2 + b * m;
+    const float gg = gdev ? gdev[0] * g : g;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx - i * n;
+        if (j < i) continue;
+        const int k = i * n - (i * (i - 1)) / 2 + (j - i);
+        const float p = o[k], t = a[idx];
+        const float q = (1.f - p) * p;
+        const float gi = gg * (p - t) / fmaxf(q, 1e-12f);
+        d[k] = through_sigmoid ? gi * q : gi;
+    }
+}
+
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ out,
+                                                          const float* __restrict__ dout, int64_t total,
+                                                          float* __restrict__ dy)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float p = out[i];
+    dy[i] = dout[i] * ((1.f - p) * p);
+}
+
+// ---------------------------------------------------------------------------
+// Adam (torch.optim.Adam arithmetic, no weight decay / amsgrad).
+// state: [0] step (as float bits of an int32), [1] lr/bc1, [2] 1/sqrt(bc2)
+// ---------------------------------------------------------------------------
+struct AdamState {
+    int32_t step;
+    float step_size;
+    float inv_sqrt_bc2;
+    float pad;
+};
+
+__global__ void adam_prepare_kernel(AdamState* st, float lr, float b1, float b2)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t step = st->step + 1;
+    st->step = step;
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    st->step_size = (float)((double)lr / bc1);
+    st->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   const AdamState* __restrict__ st, float b1, float b2, float eps,
+                                                   float gscale)
+{
+    const float step_size = st->step_size, isb = st->inv_sqrt_bc2;
+    const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 3 < n) {
+        f32x4 pp = *reinterpret_cast<f32x4*>(p + i4);
+        f32x4 gg = *reinterpret_cast<const f32x4*>(g + i4);
+        f32x4 mm = *reinterpret_cast<f32x4*>(m + i4);
+        f32x4 vv = *reinterpret_cast<f32x4*>(v + i4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gg[e] * gscale;
+            mm[e] = mm[e] + (1.f - b1) * (ge - mm[e]);
+            vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+            pp[e] = pp[e] - step_size * (mm[e] / (sqrtf(vv[e]) * isb + eps));
+        }
+        *reinterpret_cast<f32x4*>(p + i4) = pp;
+        *reinterpret_cast<f32x4*>(m + i4) = mm;
+        *reinterpret_cast<f32x4*>(v + i4) = vv;
+    } else {
+        for (int64_t i = i4; i < n; ++i) {
+            const float ge = g[i] * gscale;
+            const float me = m[i] + (1.f - b1) * (ge - m[i]);
+            const float ve = b2 * v[i] + (1.f - b2) * ge * ge;
+            m[i] = me;
+            v[i] = ve;
+            p[i] = p[i] - step_size * (me / (sqrtf(ve) * isb + eps));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// edge precision / recall against a gold edge bitmask.
+// gold_bits[g*n + a] has bit b set iff (a,b) is a gold edge.
+// per-graph: hits = #pred (a,b) with (a,b) or (b,a) in gold;
+// recall = hits/|gold|, precision = hits/|pred|, both 1 when either is empty.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_prf_kernel(const int32_t* __restrict__ edges,
+                                                       const int32_t* __restrict__ count,
+                                                       const uint64_t* __restrict__ gold, int64_t G, int n,
+                                                       float* __restrict__ recall, float* __restrict__ precision)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint64_t* gb = gold + g * n;
+    int ngold = 0;
+    for (int a = 0; a < n; ++a) ngold += __popcll(gb[a]);
+    const int npred = count[g];
+    const int32_t* e = edges + g * 2 * (n - 1);
+    int hits = 0;
+    for (int k = 0; k < npred; ++k) {
+        const int a = e[2 * k], b = e[2 * k + 1];
+        if (((gb[a] >> b) & 1ull) || ((gb[b] >> a) & 1ull)) ++hits;
+    }
+    if (ngold == 0 || npred == 0) {
+        recall[g] = 1.f;
+        precision[g] = 1.f;
+    } else {
+        recall[g] = (float)((double)hits / (double)ngold);
+        precision[g] = (float)((double)hits / (double)npred);
+    }
+}
+
+}  // namespace
+
+// ===========================================================================
+// host launchers
+// ===========================================================================
+int adj_count(const int64_t* ei, int64_t E, int64_t B, int n, int32_t* counts, int32_t* err, hipStream_t s)
+{
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)B * n * n, s) != hipSuccess ||
+        hipMemsetAsync(err, 0, sizeof(int32_t), s) != hipSuccess)
+        return set_error(GTG_ERR_LAUNCH, "adj_count: memset failed");
+    if (E == 0) return GTG_OK;
+    hipLaunchKernelGGL(adj_count_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, ei, E, B, n, counts, err);
+    return check_launch("adj_count_kernel");
+}
+
+int adj_normalize(const int32_t* counts, int64_t B, int n, float* adj, hipStream_t s)
+{
+    if (B == 0) return GTG_OK;
+    hipLaunchKernelGGL(adj_normalize_kernel, dim3((unsigned)B), dim3(64), 0, s, counts, n, adj);
+    return check_launch("adj_normalize_kernel");
+}
+
+int pool_bwd_gather(const float* adj, const float* dpool, const int32_t* argmax, int64_t B, int n, int d, float* dT2,
+                    hipStream_t s)
+{
+    if (B == 0 || d == 0) return GTG_OK;
+    hipLaunchKernelGGL(pool_bwd_gather_kernel, dim3((d + 255) / 256, (unsigned)B), dim3(256), 0, s, adj, dpool, argmax,
+                       n, d, dT2);
+    return check_launch("pool_bwd_gather_kernel");
+}
+
+size_t colsum_workspace(int64_t rows, int cols)
+{
+    const int chunk = cs_chunk_rows(rows);
+    const int64_t nchunks = (rows + chunk - 1) / chunk;
+    return (size_t)nchunks * cols * sizeof(float);
+}
+
+int colsum(const float* X, int64_t rows, int cols, int ld, float* partial, float* out, hipStream_t s)
+{
+    if (cols == 0) return GTG_OK;
+    const int chunk = cs_chunk_rows(rows);
+    const int nchunks = (int)((rows + chunk - 1) / chunk);
+    if (nchunks > 0) {
+        hipLaunchKernelGGL(colsum_stage1, dim3((cols + CS_COLS - 1) / CS_COLS, nchunks), dim3(256), 0, s, X, rows, cols,
+                           ld, chunk, partial);
+        int rc = check_launch("colsum_stage1");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(colsum_stage2, dim3((cols + 255) / 256), dim3(256), 0, s, partial, nchunks, cols, out);
+    return check_launch("colsum_stage2");
+}
+
+int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z, float* kl_partial,
+               float* kl_out, hipStream_t s)
+{
+    const int64_t total = B * d;
+    const int64_t nb = (total + 255) / 256;
+    if (nb > 0) {
+        hipLaunchKernelGGL(reparam_kl_kernel, dim3((unsigned)nb), dim3(256), 0, s, mu, logvar, eps, total, z,
+                           kl_partial);
+        int rc = check_launch("reparam_kl_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, kl_partial, nb, B > 0 ? -0.5f / (float)B : 0.f,
+                       kl_out);
+    return check_launch("final_sum_kernel");
+}
+
+int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const float* eps, const float* kl_w_dev,
+                    float kl_w, int64_t B, int d, float* dmu, float* dlogvar, hipStream_t s)
+{
+    const int64_t total = B * d;
+    if (total == 0) return GTG_OK;
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dz, mu, logvar, eps,
+                       kl_w_dev, kl_w, 1.f / (float)B, total, dmu, dlogvar);
+    return check_launch("latent_bwd_kernel");
+}
+
+int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, hipStream_t s)
+{
+    const int m = n * (n + 1) / 2;
+    if (B > 0) {
+        hipLaunchKernelGGL(bce_fwd_kernel, dim3((unsigned)B), dim3(256), 0, s, out, adj, n, m, row_partial);
+        int rc = check_launch("bce_fwd_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, row_partial, B,
+                       (B > 0 && m > 0) ? 1.f / ((float)B * (float)m) : 0.f, loss);
+    return check_launch("final_sum_kernel");
+}
+
+int bce_bwd(const float* out, const float* adj, int64_t B, int n, const float* gdev, float gscale,
+            int through_sigmoid, float* dy2, hipStream_t s)
+{
+    if (B == 0) return GTG_OK;
+    const int m = n * (n + 1) / 2;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)B), dim3(256), 0, s, out, adj, n, m, gdev,
+                       gscale / ((float)B * (float)m), through_sigmoid, dy2);
+    return check_launch("bce_bwd_kernel");
+}
+
+int sigmoid_bwd(const float* out, const float* dout, int64_t total, float* dy, hipStream_t s)
+{
+    if (total == 0) return GTG_OK;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, total, dy);
+    return check_launch("sigmoid_bwd_kernel");
+}
+
+int adam_stateful(float* p, const float* g, float* m, float* v, int64_t n, void* state, float lr, float b1, float b2,
+                  float eps, float gscale, hipStream_t s)
+{
+    AdamState* st = reinterpret_cast<AdamState*>(state);
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, st, lr, b1, b2);
+    int rc = check_launch("adam_prepare_kernel");
+    if (rc || n == 0) return rc;
+    const int64_t nv = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, st, b1, b2, eps,
+                       gscale);
+    return check_launch("adam_kernel");
+}
+
+int edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gold_bits, int64_t G, int n, float* recall,
+             float* precision, hipStream_t s)
+{
+    if (G == 0) return GTG_OK;
+    hipLaunchKernelGGL(edge_prf_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, edges, count, gold_bits, G,
+                       n, recall, precision);
+    return check_launch("edge_prf_kernel");
+}
+
+}  // namespace gtg

@@ -1,0 +1,87 @@
+// Internal declarations shared by the HIP translation units of libgtgvae_hip.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gtgvae.h"  // GTG_OK / GTG_ERR_* codes
+
+namespace gtg {
+
+// ---- error plumbing (no C++ exceptions cross the C ABI) --------------------
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- fp32 MFMA GEMM ---------------------------------------------------------
+// C[M,N] (+)= op(A)[M,K] * op(B)[K,N], fp32 in / fp32 accumulate on
+// v_mfma_f32_32x32x2_f32.  Operand layouts:
+//   a_kc  : A element (m,k) at A[m*lda + k]   (K contiguous);  else A[k*lda + m]
+//   b_kc  : B element (k,n) at B[n*ldb + k]   (K contiguous);  else B[k*ldb + n]
+enum GemmEpilogue : int {
+    EPI_STORE = 0,     // C = acc (+ bias[n])
+    EPI_RELU = 1,      // C = max(acc + bias[n], 0)
+    EPI_SIGMOID = 2,   // C = 1/(1+exp(-(acc + bias[n])))
+    EPI_MASK = 3,      // C = aux[m,n] > 0 ? acc : 0
+    EPI_ACCUM = 4,     // C += acc
+    EPI_POOL = 5,      // per batch: pool_val[b,n] = max_m (acc + bias[n]), pool_idx = argmax (lowest m on ties)
+};
+
+struct GemmDesc {
+    const float* A = nullptr;
+    const float* B = nullptr;
+    float* C = nullptr;
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldb = 0, ldc = 0;
+    bool a_kc = true, b_kc = true;
+    int batch = 1;
+    long long strideA = 0, strideB = 0, strideC = 0;
+    int epi = EPI_STORE;
+    const float* bias = nullptr;
+    const float* aux = nullptr;
+    int ldaux = 0;
+    long long strideAux = 0;
+    float* pool_val = nullptr;   // (batch, N)
+    int32_t* pool_idx = nullptr; // (batch, N)
+    // split-K: when splits > 1 the kernel writes `splits` partial slabs of
+    // M*N floats into `slabs` and a second kernel sums them in slab order into C
+    // (bitwise reproducible; no float atomics).
+    int splits = 1;
+    float* slabs = nullptr;
+};
+
+// Bytes of slab workspace gemm() needs for this shape (0 when it will not split).
+size_t gemm_splitk_workspace(int M, int N, int K, int batch);
+int gemm_pick_splits(int M, int N, int K, int batch);
+int gemm(const GemmDesc& d, hipStream_t s);
+
+// ---- element-wise / reduction kernels (graph_ops.hip) -----------------------
+int adj_count(const int64_t* edge_index, int64_t E, int64_t B, int n, int32_t* counts, int32_t* err, hipStream_t s);
+int adj_normalize(const int32_t* counts, int64_t B, int n, float* adj, hipStream_t s);
+int pool_bwd_gather(const float* adj, const float* dpool, const int32_t* argmax, int64_t B, int n, int d,
+                    float* dT2, hipStream_t s);
+int colsum(const float* X, int64_t rows, int cols, int ld, float* partial, float* out, hipStream_t s);
+size_t colsum_workspace(int64_t rows, int cols);
+int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z,
+               float* kl_partial, float* kl_out, hipStream_t s);
+int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const float* eps, const float* kl_scale_dev,
+                    float kl_scale, int64_t B, int d, float* dmu, float* dlogvar, hipStream_t s);
+int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, hipStream_t s);
+// gdev (nullable) is a device scalar multiplied into gscale (an upstream gradient).
+// through_sigmoid = 1: gradient w.r.t. the pre-sigmoid logits (BCE backward, then
+// the sigmoid's backward); 0: gradient w.r.t. the probabilities only.
+int bce_bwd(const float* out, const float* adj, int64_t B, int n, const float* gdev, float gscale,
+            int through_sigmoid, float* grad, hipStream_t s);
+// dy = dout * (1 - out) * out
+int sigmoid_bwd(const float* out, const float* dout, int64_t total, float* dy, hipStream_t s);
+// state: 16 device bytes {int32 step, float lr/bc1, float 1/sqrt(bc2), pad}; the
+// step counter lives on the device so a captured HIP graph can be replayed.
+int adam_stateful(float* p, const float* g, float* m, float* v, int64_t n, void* state, float lr, float b1, float b2,
+                  float eps, float gscale, hipStream_t s);
+int edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gold_bits, int64_t G, int n,
+             float* recall, float* precision, hipStream_t s);
+
+// ---- MST (mst.hip) ----------------------------------------------------------
+int mst_triu(const float* rows, int64_t G, int n, int32_t* edges, int32_t* count, hipStream_t s);
+int mst_full(const float* mats, int64_t G, int n, int32_t* edges, int32_t* count, hipStream_t s);
+
+}  // namespace gtg

@@ -1,0 +1,169 @@
+"""Host-side batch builder: the input contract of the hot path.
+
+Mirrors ``loaddata.prep_data_list`` (/root/reference/src/train.py:174-213) and
+the torch_geometric ``DataLoader`` collate used at train.py:549 (node features
+concatenated, edge indices offset by graph, a ``batch`` vector of graph ids),
+without depending on torch_geometric.  Also generates the synthetic AMR-shaped
+graphs used by the benchmark and the tests.
+"""
+import json
+from dataclasses import dataclass, field
+from typing import Iterable, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+import torch
+
+
+@dataclass
+class GraphData:
+    """One graph, as train.py:203-210 builds it (x is the identity and is not stored)."""
+    edge_index: torch.Tensor          # (2, E_g) int64
+    gold_edges: Set[Tuple[int, int]]
+    adj_padded: np.ndarray            # (maxnode, maxnode) float64
+    snts: str = ""
+    num_nodes: int = 0
+    maxnode: int = 0
+
+    @property
+    def x(self) -> torch.Tensor:
+        return torch.eye(self.maxnode, dtype=torch.float)
+
+
+def prep_graph(graph: dict, maxnode: int) -> Optional[GraphData]:
+    """train.py:177-211 for one MRP graph dict; None when the graph is skipped."""
+    num_of_nodes = len(graph["nodes"])
+    if num_of_nodes > maxnode or "edges" not in graph:
+        return None
+    edges: List[Tuple[int, int]] = []
+    seen = set()
+    gold = []
+    adj = np.zeros((num_of_nodes, num_of_nodes))
+    for edge in graph["edges"]:
+        s, t = edge["source"], edge["target"]
+        # both directions are appended every time (duplicates kept, train.py:187-188);
+        # a self loop is appended only if that pair is not in the list yet (train.py:189-192)
+        for pair in ((s, t), (t, s)):
+            edges.append(pair)
+            seen.add(pair)
+        for v in (s, t):
+            if (v, v) not in seen:
+                edges.append((v, v))
+                seen.add((v, v))
+        if s != t:
+            gold.append((s, t))
+            adj[s, t] = 1
+            adj[t, s] = 1
+    adj = adj + np.identity(num_of_nodes)
+    adj_padded = np.zeros((maxnode, maxnode))
+    adj_padded[:num_of_nodes, :num_of_nodes] = adj
+    ei = torch.tensor(edges, dtype=torch.long).reshape(-1, 2).t().contiguous()
+    return GraphData(ei, set(gold), adj_padded, graph.get("input", ""), num_of_nodes, maxnode)
+
+
+def prep_data_list(graphs: Iterable[dict], maxnode: int) -> List[GraphData]:
+    out = []
+    for g in graphs:
+        d = prep_graph(g, maxnode)
+        if d is not None:
+            out.append(d)
+    return out
+
+
+def load_mrp(path: str) -> List[dict]:
+    """One JSON object per line (train.py:218-221)."""
+    with open(path, "r") as f:
+        return [json.loads(l) for l in f if l.strip()]
+
+
+@dataclass
+class GraphBatch:
+    """A collated batch.  ``x`` is None: node features are stacked identities
+    (train.py:203-204), which the encoder exploits; ``dense_x()`` materialises
+    them for callers that want the reference's tensor."""
+    edge_index: torch.Tensor            # (2, E) int64, node id = graph * nmax + local id
+    batch: torch.Tensor                 # (B * nmax,) int64 graph id per node
+    adj_padded: torch.Tensor            # (B, nmax, nmax) float32 reconstruction targets
+    gold_edges: List[Set[Tuple[int, int]]]
+    snts: List[str]
+    num_graphs: int
+    nmax: int
+    num_nodes: torch.Tensor = None      # (B,) int32
+    x: Optional[torch.Tensor] = None
+    gold_bits: Optional[torch.Tensor] = field(default=None)  # (B, nmax) int64 bit masks
+
+    def dense_x(self) -> torch.Tensor:
+        return torch.eye(self.nmax, dtype=torch.float, device=self.edge_index.device).repeat(self.num_graphs, 1)
+
+    def to(self, device) -> "GraphBatch":
+        mv = lambda t: None if t is None else t.to(device, non_blocking=True)
+        return GraphBatch(mv(self.edge_index), mv(self.batch), mv(self.adj_padded), self.gold_edges, self.snts,
+                          self.num_graphs, self.nmax, mv(self.num_nodes), mv(self.x), mv(self.gold_bits))
+
+    def __len__(self):
+        return self.num_graphs
+
+
+def gold_bitmask(gold_edges: Sequence[Set[Tuple[int, int]]], nmax: int) -> torch.Tensor:
+    """(B, nmax) int64: bit b of word [g, a] is set iff (a, b) is a gold edge of graph g."""
+    out = np.zeros((len(gold_edges), nmax), dtype=np.uint64)
+    for g, es in enumerate(gold_edges):
+        for a, b in es:
+            out[g, a] |= np.uint64(1) << np.uint64(b)
+    return torch.from_numpy(out.view(np.int64))
+
+
+def collate(data_list: Sequence[GraphData], nmax: int) -> GraphBatch:
+    B = len(data_list)
+    eis = [d.edge_index + g * nmax for g, d in enumerate(data_list)]
+    ei = torch.cat(eis, dim=1) if eis else torch.zeros((2, 0), dtype=torch.long)
+    batch = torch.arange(B, dtype=torch.long).repeat_interleave(nmax)
+    adj = torch.from_numpy(np.stack([d.adj_padded for d in data_list])).float() if B else torch.zeros((0, nmax, nmax))
+    gold = [d.gold_edges for d in data_list]
+    nn = torch.tensor([d.num_nodes for d in data_list], dtype=torch.int32)
+    return GraphBatch(ei.contiguous(), batch, adj, gold, [d.snts for d in data_list], B, nmax, nn, None,
+                      gold_bitmask(gold, nmax))
+
+
+class DataLoader:
+    """Minimal stand-in for torch_geometric's DataLoader(dataset, batch_size) (train.py:549-550)."""
+
+    def __init__(self, dataset: Sequence[GraphData], batch_size: int, nmax: int = None, shuffle: bool = False, seed: int = 0):
+        self.dataset = list(dataset)
+        self.batch_size = batch_size
+        self.nmax = nmax if nmax is not None else (self.dataset[0].maxnode if self.dataset else 0)
+        self.shuffle = shuffle
+        self._rng = np.random.default_rng(seed)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = np.arange(len(self.dataset))
+        if self.shuffle:
+            self._rng.shuffle(order)
+        for i in range(0, len(order), self.batch_size):
+            yield collate([self.dataset[j] for j in order[i:i + self.batch_size]], self.nmax)
+
+
+# ---------------------------------------------------------------------------
+# synthetic AMR-shaped graphs
+# ---------------------------------------------------------------------------
+def synth_mrp_graph(rng: np.random.Generator, nmax: int) -> dict:
+    """n ~ U{max(2, nmax/4) .. nmax}; a random recursive tree plus floor(0.15 n)
+    re-entrancy edges between random distinct nodes (duplicates allowed)."""
+    lo = max(2, nmax // 4)
+    n = int(rng.integers(lo, nmax + 1)) if nmax >= lo else nmax
+    edges = [{"source": int(rng.integers(0, t)), "target": t} for t in range(1, n)]
+    for _ in range(int(0.15 * n)):
+        a, b = rng.choice(n, size=2, replace=False)
+        edges.append({"source": int(a), "target": int(b)})
+    return {"nodes": [{"id": i} for i in range(n)], "edges": edges, "input": "synthetic sentence %d" % n}
+
+
+def synth_graph_list(num: int, nmax: int, seed: int = 1234) -> List[GraphData]:
+    rng = np.random.default_rng(seed)
+    return prep_data_list([synth_mrp_graph(rng, nmax) for _ in range(num)], nmax)
+
+
+def synth_graph_batch(B: int, nmax: int, seed: int = 1234) -> GraphBatch:
+    return collate(synth_graph_list(B, nmax, seed), nmax)

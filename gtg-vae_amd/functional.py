@@ -1,0 +1,272 @@
+"""torch.autograd.Function wrappers over the C ABI (include/gtgvae.h).
+
+PyTorch is used for device memory, streams and the autograd graph only; every
+arithmetic step of forward and backward runs in csrc/*.hip.  All tensors must
+be fp32 and on the GPU; there is no fallback.
+"""
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    _lib.require_cuda(t)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------
+# adjacency
+# ---------------------------------------------------------------------------
+def build_adj(edge_index: torch.Tensor, num_graphs: int, nmax: int, check_edges: bool = False) -> torch.Tensor:
+    """D^-1/2 (C + I) D^-1/2 per graph, (B, nmax, nmax) fp32, from a PyG-style
+    batched edge_index (2, E) int64.  With check_edges the error flag is read
+    back (a host sync) and an exception raised if an edge leaves its graph."""
+    _lib.require_cuda(edge_index)
+    ei = edge_index.contiguous()
+    if ei.dtype != torch.int64:
+        ei = ei.long()
+    dev = ei.device
+    counts = torch.empty((num_graphs * nmax * nmax,), dtype=torch.int32, device=dev)
+    err = torch.empty((1,), dtype=torch.int32, device=dev)
+    adj = torch.empty((num_graphs, nmax, nmax), dtype=torch.float32, device=dev)
+    check(_lib.lib().gtg_adj_build(ptr(ei), ei.shape[1], num_graphs, nmax, ptr(counts), ptr(err), ptr(adj), stream_ptr()),
+          "gtg_adj_build")
+    if check_edges and int(err.item()) != 0:
+        raise _lib.GtgError("edge_index holds an edge whose endpoints are out of range or in different graphs")
+    return adj
+
+
+# ---------------------------------------------------------------------------
+# encoder
+# ---------------------------------------------------------------------------
+class EncoderFn(torch.autograd.Function):
+    """pooled (B, d) = global_max_pool(GCN2(relu(GCN1(x))))."""
+
+    @staticmethod
+    def forward(ctx, adj, x, W1, b1, W2, b2):
+        L = _lib.lib()
+        adj, x, W1, b1, W2, b2 = map(_f32c, (adj, x, W1, b1, W2, b2))
+        B, n, _ = adj.shape
+        H, f = W1.shape
+        d = W2.shape[0]
+        if H != 2 * d or W2.shape[1] != H:
+            raise _lib.GtgError("encoder weights must be W1 (2d, f), W2 (d, 2d)")
+        if x is not None and tuple(x.shape) != (B * n, f):
+            raise _lib.GtgError(f"x must be (B*n, f) = ({B * n}, {f}), got {tuple(x.shape)}")
+        dev = adj.device
+        h1 = torch.empty((B * n, H), dtype=torch.float32, device=dev)
+        pooled = torch.empty((B, d), dtype=torch.float32, device=dev)
+        argmax = torch.empty((B, d), dtype=torch.int32, device=dev)
+        nb = L.gtg_encoder_fwd_workspace_bytes(B, n, f, d, int(x is not None))
+        ws = _ws(nb, dev)
+        check(L.gtg_encoder_fwd(ptr(adj), ptr(x), ptr(W1), ptr(b1), ptr(W2), ptr(b2), B, n, f, d, ptr(h1), ptr(pooled),
+                                ptr(argmax), ptr(ws), ws.numel(), stream_ptr()), "gtg_encoder_fwd")
+        ctx.save_for_backward(adj, x, W1, W2, h1, argmax)
+        ctx.dims = (B, n, f, d)
+        ctx.mark_non_differentiable(argmax)
+        return pooled, argmax
+
+    @staticmethod
+    def backward(ctx, dpooled, _dargmax):
+        L = _lib.lib()
+        adj, x, W1, W2, h1, argmax = ctx.saved_tensors
+        B, n, f, d = ctx.dims
+        dev = adj.device
+        dpooled = _f32c(dpooled)
+        dW1 = torch.empty_like(W1)
+        db1 = torch.empty((2 * d,), dtype=torch.float32, device=dev)
+        dW2 = torch.empty_like(W2)
+        db2 = torch.empty((d,), dtype=torch.float32, device=dev)
+        nb = L.gtg_encoder_bwd_workspace_bytes(B, n, f, d, int(x is not None))
+        ws = _ws(nb, dev)
+        check(L.gtg_encoder_bwd(ptr(adj), ptr(x), ptr(W1), ptr(W2), ptr(h1), ptr(argmax), ptr(dpooled), B, n, f, d,
+                                ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(ws), ws.numel(), stream_ptr()),
+              "gtg_encoder_bwd")
+        # node features and the adjacency are inputs, not parameters: no gradient
+        return None, None, dW1, db1, dW2, db2
+
+
+# ---------------------------------------------------------------------------
+# latent head
+# ---------------------------------------------------------------------------
+class LatentFn(torch.autograd.Function):
+    """(z, kl, mu, logvar) from h with eps supplied; mu/logvar are returned for
+    inspection only (non-differentiable outputs)."""
+
+    @staticmethod
+    def forward(ctx, h, Wmu, bmu, Wlv, blv, eps):
+        L = _lib.lib()
+        h, Wmu, bmu, Wlv, blv, eps = map(_f32c, (h, Wmu, bmu, Wlv, blv, eps))
+        B, d = h.shape
+        dev = h.device
+        mu = torch.empty((B, d), dtype=torch.float32, device=dev)
+        lv = torch.empty_like(mu)
+        z = torch.empty_like(mu)
+        kl = torch.empty((), dtype=torch.float32, device=dev)
+        ws = _ws(L.gtg_latent_workspace_bytes(B, d), dev)
+        check(L.gtg_latent_fwd(ptr(h), ptr(Wmu), ptr(bmu), ptr(Wlv), ptr(blv), ptr(eps), B, d, ptr(mu), ptr(lv), ptr(z),
+                               ptr(kl), ptr(ws), ws.numel(), stream_ptr()), "gtg_latent_fwd")
+        ctx.save_for_backward(h, Wmu, Wlv, mu, lv, eps)
+        ctx.mark_non_differentiable(mu, lv)
+        return z, kl, mu, lv
+
+    @staticmethod
+    def backward(ctx, dz, dkl, _dmu, _dlv):
+        L = _lib.lib()
+        h, Wmu, Wlv, mu, lv, eps = ctx.saved_tensors
+        B, d = h.shape
+        dev = h.device
+        dz = _f32c(dz)
+        dkl = _f32c(dkl) if dkl is not None else None
+        dWmu = torch.empty_like(Wmu)
+        dWlv = torch.empty_like(Wlv)
+        dbmu = torch.empty((d,), dtype=torch.float32, device=dev)
+        dblv = torch.empty((d,), dtype=torch.float32, device=dev)
+        dh = torch.empty_like(h)
+        ws = _ws(L.gtg_latent_workspace_bytes(B, d), dev)
+        kl_w = 1.0 if dkl is not None else 0.0
+        check(L.gtg_latent_bwd(ptr(h), ptr(Wmu), ptr(Wlv), ptr(mu), ptr(lv), ptr(eps), ptr(dz), kl_w, ptr(dkl), B, d,
+                               ptr(dWmu), ptr(dbmu), ptr(dWlv), ptr(dblv), ptr(dh), ptr(ws), ws.numel(), stream_ptr()),
+              "gtg_latent_bwd")
+        return dh, dWmu, dbmu, dWlv, dblv, None
+
+
+class ReparamKLFn(torch.autograd.Function):
+    """(z, kl) from (mu, logvar, eps): GTVAE.reparameterize + GTVAE.loss_kl."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        L = _lib.lib()
+        mu, logvar, eps = map(_f32c, (mu, logvar, eps))
+        B, d = mu.shape
+        z = torch.empty_like(mu)
+        kl = torch.empty((), dtype=torch.float32, device=mu.device)
+        ws = _ws(L.gtg_latent_workspace_bytes(B, d), mu.device)
+        check(L.gtg_reparam_kl_fwd(ptr(mu), ptr(logvar), ptr(eps), B, d, ptr(z), ptr(kl), ptr(ws), ws.numel(),
+                                   stream_ptr()), "gtg_reparam_kl_fwd")
+        ctx.save_for_backward(mu, logvar, eps)
+        return z, kl
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        L = _lib.lib()
+        mu, logvar, eps = ctx.saved_tensors
+        B, d = mu.shape
+        dz = _f32c(dz)
+        dkl = _f32c(dkl) if dkl is not None else None
+        dmu = torch.empty_like(mu)
+        dlv = torch.empty_like(mu)
+        check(L.gtg_reparam_kl_bwd(ptr(mu), ptr(logvar), ptr(eps), ptr(dz), 1.0 if dkl is not None else 0.0, ptr(dkl),
+                                   B, d, ptr(dmu), ptr(dlv), stream_ptr()), "gtg_reparam_kl_bwd")
+        return dmu, dlv, None
+
+
+# ---------------------------------------------------------------------------
+# decoder and reconstruction loss
+# ---------------------------------------------------------------------------
+class DecoderFn(torch.autograd.Function):
+    """out (B, M) = sigmoid(relu(z D1^T + c1) D2^T + c2)."""
+
+    @staticmethod
+    def forward(ctx, z, D1, c1, D2, c2):
+        L = _lib.lib()
+        z, D1, c1, D2, c2 = map(_f32c, (z, D1, c1, D2, c2))
+        B, d = z.shape
+        hid = D1.shape[0]
+        m_out = D2.shape[0]
+        y1 = torch.empty((B, hid), dtype=torch.float32, device=z.device)
+        out = torch.empty((B, m_out), dtype=torch.float32, device=z.device)
+        check(L.gtg_decoder_fwd(ptr(z), ptr(D1), ptr(c1), ptr(D2), ptr(c2), B, d, hid, m_out, ptr(y1), ptr(out),
+                                stream_ptr()), "gtg_decoder_fwd")
+        ctx.save_for_backward(z, D1, D2, y1, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        z, D1, D2, y1, out = ctx.saved_tensors
+        B, d = z.shape
+        hid, m_out = D1.shape[0], D2.shape[0]
+        dev = z.device
+        dout = _f32c(dout)
+        dD1 = torch.empty_like(D1)
+        dD2 = torch.empty_like(D2)
+        dc1 = torch.empty((hid,), dtype=torch.float32, device=dev)
+        dc2 = torch.empty((m_out,), dtype=torch.float32, device=dev)
+        dz = torch.empty_like(z)
+        ws = _ws(L.gtg_decoder_bwd_workspace_bytes(B, d, hid, m_out), dev)
+        check(L.gtg_decoder_bwd(ptr(z), ptr(D1), ptr(D2), ptr(y1), ptr(out), ptr(dout), None, 0, 1.0, None, B, d, hid,
+                                m_out, ptr(dD1), ptr(dc1), ptr(dD2), ptr(dc2), ptr(dz), ptr(ws), ws.numel(),
+                                stream_ptr()), "gtg_decoder_bwd")
+        return dz, dD1, dc1, dD2, dc2
+
+
+class BCELossFn(torch.autograd.Function):
+    """mean_b mean_k BCE(out[b,k], triu(adj[b])[k]) (log clamped at -100)."""
+
+    @staticmethod
+    def forward(ctx, out, adj):
+        L = _lib.lib()
+        out, adj = _f32c(out), _f32c(adj)
+        B, m = out.shape
+        n = adj.shape[-1]
+        if tuple(adj.shape) != (B, n, n) or m != n * (n + 1) // 2:
+            raise _lib.GtgError(f"out {tuple(out.shape)} / adj {tuple(adj.shape)} do not match (B, n(n+1)/2) / (B, n, n)")
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        ws = _ws(L.gtg_bce_workspace_bytes(B), out.device)
+        check(L.gtg_bce_loss_fwd(ptr(out), ptr(adj), B, n, ptr(loss), ptr(ws), ws.numel(), stream_ptr()),
+              "gtg_bce_loss_fwd")
+        ctx.save_for_backward(out, adj)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        out, adj = ctx.saved_tensors
+        B, n = adj.shape[0], adj.shape[-1]
+        g = _f32c(g)
+        dout = torch.empty_like(out)
+        check(L.gtg_bce_loss_bwd(ptr(out), ptr(adj), 1.0, ptr(g), B, n, 0, ptr(dout), stream_ptr()),
+              "gtg_bce_loss_bwd")
+        return dout, None
+
+
+def edge_precision_recall(edges: torch.Tensor, count: torch.Tensor, gold_bits: torch.Tensor, nmax: int):
+    """Per-graph (recall, precision) fp32 tensors on the GPU."""
+    _lib.require_cuda(edges, count, gold_bits)
+    G = count.shape[0]
+    rec = torch.empty((G,), dtype=torch.float32, device=edges.device)
+    prec = torch.empty_like(rec)
+    check(_lib.lib().gtg_edge_prf(ptr(edges.contiguous()), ptr(count.contiguous()), ptr(gold_bits.contiguous()), G,
+                                  nmax, ptr(rec), ptr(prec), stream_ptr()), "gtg_edge_prf")
+    return rec, prec
+
+
+def gemm(A, B, a_kc=True, b_kc=True, bias=None, epilogue=0, aux=None, out=None, M=None, N=None, K=None,
+         split_k=True):
+    """Thin test/profiling hook over gtg_gemm_f32 (see include/gtgvae.h)."""
+    L = _lib.lib()
+    A, B = _f32c(A), _f32c(B)
+    if M is None:
+        M, K = (A.shape[0], A.shape[1]) if a_kc else (A.shape[1], A.shape[0])
+        N = B.shape[0] if b_kc else B.shape[1]
+    C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
+    slabs = None
+    nb = L.gtg_gemm_splitk_workspace_bytes(M, N, K) if split_k else 0
+    if nb:
+        slabs = _ws(nb, A.device)
+    check(L.gtg_gemm_f32(ptr(A), ptr(B), ptr(C), M, N, K, A.stride(0), B.stride(0), C.stride(0), int(a_kc), int(b_kc),
+                         ptr(_f32c(bias)), epilogue, ptr(_f32c(aux)), aux.stride(0) if aux is not None else 0,
+                         ptr(slabs), nb, stream_ptr()), "gtg_gemm_f32")
+    return C

@@ -1,0 +1,89 @@
+"""Data-parallel plumbing: shard a batch by graph, all-reduce flat gradient
+buckets (RCCL over xGMI on the GPU; gloo in the CPU tests).
+
+The reference is single-process (no DDP/NCCL call exists in it); this layer
+is new.  One process per GPU; every rank holds the full replicated parameter
+and optimiser state; each step exchanges exactly the flat fp32 gradient
+buffer, split in two buckets so that the first (decoder + latent head, whose
+gradients are final before the encoder's backward starts) is reduced while
+the encoder's backward GEMMs still run.
+"""
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(num_graphs: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of a global batch; sizes differ by at most one."""
+    base, rem = divmod(num_graphs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GradBuckets:
+    """Views of one flat gradient buffer, reduced bucket by bucket.
+
+    ``bounds`` are element offsets [0, b1, ..., numel].  ``reduce(i)`` launches
+    the sum all-reduce of bucket i asynchronously; ``finish()`` waits for all of
+    them.  The 1/world scaling is left to the optimiser kernel (it multiplies
+    the gradient by ``scale`` on load), so no extra pass over the buffer runs.
+    """
+
+    def __init__(self, flat_grad: torch.Tensor, bounds: Sequence[int], group=None):
+        assert bounds[0] == 0 and bounds[-1] == flat_grad.numel()
+        self.flat = flat_grad
+        self.views = [flat_grad[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._pending: List = []
+
+    @property
+    def scale(self) -> float:
+        return 1.0 / self.world
+
+    def reduce(self, i: int) -> None:
+        if self.world == 1:
+            return
+        self._pending.append(dist.all_reduce(self.views[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
+
+    def reduce_all(self) -> None:
+        for i in range(len(self.views)):
+            self.reduce(i)
+        self.finish()
+
+
+def all_reduce_scalars(values: torch.Tensor, group=None) -> torch.Tensor:
+    """Mean of a small tensor of per-rank scalars (reporting only)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+        values = values / dist.get_world_size(group)
+    return values

@@ -1,0 +1,81 @@
+"""Text branch of the joint model (denoising LSTM auto-encoder).
+
+Mirrors /root/reference/src/text_vae.py:22-132 (``TextModel``, ``DAE``): same
+sub-module names and shapes, hence the same ``state_dict`` keys
+(``embed, proj, E, G, hgen, z2emb``).  It runs on stock PyTorch-ROCm
+LSTM/GEMM kernels: the text branch sits outside the graph hot path, it is
+here so that ``GTVAE.forward`` keeps the reference's joint behaviour.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .noise import noisy
+
+
+class TextModel(nn.Module):
+    def __init__(self, vocabsize, initrange=0.1):
+        super().__init__()
+        self.embed = nn.Embedding(vocabsize, 512)
+        self.proj = nn.Linear(1024, vocabsize)
+        with torch.no_grad():
+            self.embed.weight.uniform_(-initrange, initrange)
+            self.proj.bias.zero_()
+            self.proj.weight.uniform_(-initrange, initrange)
+
+
+class DAE(TextModel):
+    def __init__(self, latent_dim, vocabsize, padidx):
+        super().__init__(vocabsize)
+        self.drop = nn.Dropout(0.5)
+        self.E = nn.LSTM(512, 1024, 1, dropout=0.0, bidirectional=True)
+        self.G = nn.LSTM(512, 1024, 1, dropout=0.0)
+        self.hgen = nn.Linear(2048, latent_dim)
+        self.z2emb = nn.Linear(latent_dim, 512)
+        self.padidx = padidx
+
+    def flatten(self):
+        self.E.flatten_parameters()
+        self.G.flatten_parameters()
+
+    def encode(self, input):
+        emb = self.drop(self.embed(input))
+        _, (ht, _) = self.E(emb)
+        return self.hgen(torch.cat([ht[-2], ht[-1]], 1))
+
+    def decode(self, z, input, hidden=None):
+        emb = self.drop(self.embed(input)) + self.z2emb(z)
+        output, hidden = self.G(emb, hidden)
+        output = self.drop(output)
+        logits = self.proj(output.view(-1, output.size(-1)))
+        return logits.view(output.size(0), output.size(1), -1), hidden
+
+    def forward(self, input):
+        _input = noisy(self.padidx, input, 0.3, 0, 0, 0) if self.training else input
+        return self.encode(_input)
+
+    def loss_rec(self, logits, targets):
+        loss = F.cross_entropy(logits.view(-1, logits.size(-1)), targets.flatten(), ignore_index=self.padidx,
+                               reduction="none").view(targets.size())
+        return loss.sum(dim=0)
+
+    def accuracy(self, logits, targets, is_dev=False):
+        pred = torch.argmax(logits, 2)  # softmax is monotone: same arg-max as text_vae.py:83-84
+        mask = targets != self.padidx
+        return (((pred == targets) & mask).sum() / mask.sum()).item()
+
+    def autoenc(self, inputs, targets):
+        return self(inputs)
+
+    def generate(self, z, max_len, alg):
+        sents = []
+        input = torch.full((1, len(z)), 2, dtype=torch.long, device=z.device)
+        hidden = None
+        for _ in range(max_len):
+            sents.append(input)
+            logits, hidden = self.decode(z, input, hidden)
+            if alg == "greedy":
+                input = logits.argmax(dim=-1)
+            elif alg == "sample":
+                input = torch.multinomial(logits.squeeze(dim=0).exp(), num_samples=1).t()
+        return sents

@@ -1,0 +1,255 @@
+"""Fused graph-VAE training step: forward, loss, backward and Adam as a fixed
+sequence of C-ABI calls over preallocated device buffers (no autograd, no
+allocation per step), optionally replayed as one HIP graph, data-parallel
+over one process per GPU.
+
+The step optimises  graph_recon + kl_w * KL  with joint_h := graph_h — the
+reference's own pieces (graph_vae.py:22-73, gtvae.py:33-42, 107-113, 122-123)
+composed with the reconstruction term that gtvae.py:124 leaves commented out,
+and Adam(lr=1e-3, betas=(0.5, 0.999)) as train.py:290.  The module classes in
+graph_vae.py / gtvae.py run the same kernels through autograd; this class is
+the throughput path the benchmark and the training loop use.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+from .data import GraphBatch
+from .parallel import GradBuckets
+
+# (state_dict key, shape as a function of (f, d, hid, m)); bucket 0 = decoder +
+# latent head (gradients final before the encoder's backward starts), bucket 1 = encoder.
+_PARAM_ORDER = (
+    ("decoder.decode_1.weight", lambda f, d, h, m: (h, d)),
+    ("decoder.decode_1.bias", lambda f, d, h, m: (h,)),
+    ("decoder.decode_2.weight", lambda f, d, h, m: (m, h)),
+    ("decoder.decode_2.bias", lambda f, d, h, m: (m,)),
+    ("zg_mu.weight", lambda f, d, h, m: (d, d)),
+    ("zg_mu.bias", lambda f, d, h, m: (d,)),
+    ("zg_var.weight", lambda f, d, h, m: (d, d)),
+    ("zg_var.bias", lambda f, d, h, m: (d,)),
+    ("encoder.conv1.lin.weight", lambda f, d, h, m: (2 * d, f)),
+    ("encoder.conv1.bias", lambda f, d, h, m: (2 * d,)),
+    ("encoder.conv2.lin.weight", lambda f, d, h, m: (d, 2 * d)),
+    ("encoder.conv2.bias", lambda f, d, h, m: (d,)),
+)
+_FIRST_ENCODER = "encoder.conv1.lin.weight"
+
+
+def _align(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class GraphVAETrainer:
+    def __init__(self, input_dim: int, latent_dim: int, mlp_hid_dim: int, nmax: int, device="cuda",
+                 init: Optional[Dict[str, torch.Tensor]] = None, lr: float = 1e-3, betas=(0.5, 0.999),
+                 eps: float = 1e-8, max_batch: int = 0, max_edges: int = 0, group=None, seed: int = 0):
+        if nmax > 64:
+            raise _lib.GtgError("nmax > 64 is not supported")
+        if input_dim != nmax:
+            raise _lib.GtgError("the fused step feeds identity node features: input_dim must equal nmax")
+        self.L = _lib.lib()
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise _lib.GtgError("GraphVAETrainer needs a GPU device; there is no CPU path")
+        self.f, self.d, self.hid, self.n = input_dim, latent_dim, mlp_hid_dim, nmax
+        self.m = nmax * (nmax + 1) // 2
+        self.lr, self.betas, self.eps = lr, betas, eps
+
+        # ---- flat parameter / gradient / moment buffers -----------------------
+        self.offsets: Dict[str, tuple] = {}
+        off = 0
+        split = 0
+        for name, shp in _PARAM_ORDER:
+            if name == _FIRST_ENCODER:
+                split = off
+            shape = shp(self.f, self.d, self.hid, self.m)
+            numel = 1
+            for s in shape:
+                numel *= s
+            self.offsets[name] = (off, numel, shape)
+            off = _align(off + numel)
+        self.numel = off
+        self.flat_p = torch.zeros(self.numel, dtype=torch.float32, device=self.dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.adam_state = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self.p = {k: self.flat_p[o:o + n].view(s) for k, (o, n, s) in self.offsets.items()}
+        self.g = {k: self.flat_g[o:o + n].view(s) for k, (o, n, s) in self.offsets.items()}
+        self.buckets = GradBuckets(self.flat_g, [0, split, self.numel], group)
+        self.world = self.buckets.world
+        self._init_params(init, seed)
+
+        self.kl_w_dev = torch.ones(1, dtype=torch.float32, device=self.dev)
+        self._cap_B = 0
+        self._cap_E = 0
+        self._graph = None
+        self._graph_key = None
+        if max_batch:
+            self._ensure_capacity(max_batch, max_edges or max_batch * nmax * 4)
+
+    # ------------------------------------------------------------------ params
+    def _init_params(self, init, seed):
+        if init is None:
+            # the module classes carry the reference's initialisers
+            from .gtvae import GTVAE
+
+            torch.manual_seed(seed)
+            model = GTVAE(self.f, self.d, self.hid, self.n, text=False)
+            init = {k.replace("graph_vae.", ""): v for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            for k, v in init.items():
+                k = k.replace("graph_vae.", "")
+                if k in self.p:
+                    self.p[k].copy_(v.to(self.dev, torch.float32))
+
+    def named_params(self) -> Dict[str, torch.Tensor]:
+        return self.p
+
+    def named_grads(self) -> Dict[str, torch.Tensor]:
+        return self.g
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Keys as a reference GTVAE checkpoint names them."""
+        out = {}
+        for k, v in self.p.items():
+            key = k if k.startswith("zg_") else "graph_vae." + k
+            out[key] = v.detach().clone()
+        return out
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        self._init_params(sd, 0)
+
+    # ------------------------------------------------------------------ buffers
+    def _ensure_capacity(self, B: int, E: int):
+        if B <= self._cap_B and E <= self._cap_E:
+            return
+        B = max(B, self._cap_B)
+        E = max(E, self._cap_E)
+        L, dev, n, d, hid, m, f = self.L, self.dev, self.n, self.d, self.hid, self.m, self.f
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.ei = torch.zeros((2, E), dtype=torch.int64, device=dev)
+        self.counts = torch.empty(B * n * n, dtype=torch.int32, device=dev)
+        self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.adj = torch.empty((B, n, n), **f32)
+        self.target = torch.empty((B, n, n), **f32)
+        self.eps_buf = torch.empty((B, d), **f32)
+        self.h1 = torch.empty((B * n, 2 * d), **f32)
+        self.pooled = torch.empty((B, d), **f32)
+        self.argmax = torch.empty((B, d), dtype=torch.int32, device=dev)
+        self.mu = torch.empty((B, d), **f32)
+        self.logvar = torch.empty((B, d), **f32)
+        self.z = torch.empty((B, d), **f32)
+        self.y1 = torch.empty((B, hid), **f32)
+        self.out = torch.empty((B, m), **f32)
+        self.dz = torch.empty((B, d), **f32)
+        self.dh = torch.empty((B, d), **f32)
+        self.scalars = torch.zeros(2, **f32)  # [recon, kl]
+        nbytes = max(L.gtg_encoder_fwd_workspace_bytes(B, n, f, d, 0), L.gtg_encoder_bwd_workspace_bytes(B, n, f, d, 0),
+                     L.gtg_latent_workspace_bytes(B, d), L.gtg_decoder_bwd_workspace_bytes(B, d, hid, m),
+                     L.gtg_bce_workspace_bytes(B))
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._cap_B, self._cap_E = B, E
+        self._graph = None
+
+    def load_batch(self, batch: GraphBatch, eps: torch.Tensor):
+        """Copy one batch into the step's static input buffers.  The edge list
+        is padded to capacity with (0,0) self loops, which the adjacency kernel
+        drops, so the launch shapes do not depend on the number of edges."""
+        B, E = batch.num_graphs, batch.edge_index.shape[1]
+        self._ensure_capacity(B, E)
+        self.ei[:, :E].copy_(batch.edge_index, non_blocking=True)
+        if E < self._cap_E:
+            self.ei[:, E:].zero_()
+        self.target[:B].copy_(batch.adj_padded, non_blocking=True)
+        self.eps_buf[:B].copy_(eps, non_blocking=True)
+        self._B = B
+
+    # ------------------------------------------------------------------ the step
+    def _launch(self, B: int, update: bool, stream: int):
+        L, n, d, hid, m, f = self.L, self.n, self.d, self.hid, self.m, self.f
+        p, g = self.p, self.g
+        ws, wsn = ptr(self.ws), self.ws.numel()
+        check(L.gtg_adj_build(ptr(self.ei), self.ei.shape[1], B, n, ptr(self.counts), ptr(self.err), ptr(self.adj),
+                              stream), "gtg_adj_build")
+        check(L.gtg_encoder_fwd(ptr(self.adj), None, ptr(p["encoder.conv1.lin.weight"]), ptr(p["encoder.conv1.bias"]),
+                                ptr(p["encoder.conv2.lin.weight"]), ptr(p["encoder.conv2.bias"]), B, n, f, d,
+                                ptr(self.h1), ptr(self.pooled), ptr(self.argmax), ws, wsn, stream), "gtg_encoder_fwd")
+        check(L.gtg_latent_fwd(ptr(self.pooled), ptr(p["zg_mu.weight"]), ptr(p["zg_mu.bias"]), ptr(p["zg_var.weight"]),
+                               ptr(p["zg_var.bias"]), ptr(self.eps_buf), B, d, ptr(self.mu), ptr(self.logvar),
+                               ptr(self.z), self.scalars[1:].data_ptr(), ws, wsn, stream), "gtg_latent_fwd")
+        check(L.gtg_decoder_fwd(ptr(self.z), ptr(p["decoder.decode_1.weight"]), ptr(p["decoder.decode_1.bias"]),
+                                ptr(p["decoder.decode_2.weight"]), ptr(p["decoder.decode_2.bias"]), B, d, hid, m,
+                                ptr(self.y1), ptr(self.out), stream), "gtg_decoder_fwd")
+        check(L.gtg_bce_loss_fwd(ptr(self.out), ptr(self.target), B, n, self.scalars.data_ptr(), ws, wsn, stream),
+              "gtg_bce_loss_fwd")
+        # ---- backward ---------------------------------------------------------
+        check(L.gtg_decoder_bwd(ptr(self.z), ptr(p["decoder.decode_1.weight"]), ptr(p["decoder.decode_2.weight"]),
+                                ptr(self.y1), ptr(self.out), None, ptr(self.target), n, 1.0, None, B, d, hid, m,
+                                ptr(g["decoder.decode_1.weight"]), ptr(g["decoder.decode_1.bias"]),
+                                ptr(g["decoder.decode_2.weight"]), ptr(g["decoder.decode_2.bias"]), ptr(self.dz), ws,
+                                wsn, stream), "gtg_decoder_bwd")
+        check(L.gtg_latent_bwd(ptr(self.pooled), ptr(p["zg_mu.weight"]), ptr(p["zg_var.weight"]), ptr(self.mu),
+                               ptr(self.logvar), ptr(self.eps_buf), ptr(self.dz), 1.0, ptr(self.kl_w_dev), B, d,
+                               ptr(g["zg_mu.weight"]), ptr(g["zg_mu.bias"]), ptr(g["zg_var.weight"]),
+                               ptr(g["zg_var.bias"]), ptr(self.dh), ws, wsn, stream), "gtg_latent_bwd")
+        if update and self.world > 1:
+            self.buckets.reduce(0)  # decoder + latent gradients travel while the encoder's backward runs
+        check(L.gtg_encoder_bwd(ptr(self.adj), None, ptr(p["encoder.conv1.lin.weight"]),
+                                ptr(p["encoder.conv2.lin.weight"]), ptr(self.h1), ptr(self.argmax), ptr(self.dh), B, n,
+                                f, d, ptr(g["encoder.conv1.lin.weight"]), ptr(g["encoder.conv1.bias"]),
+                                ptr(g["encoder.conv2.lin.weight"]), ptr(g["encoder.conv2.bias"]), ws, wsn, stream),
+              "gtg_encoder_bwd")
+        if update:
+            if self.world > 1:
+                self.buckets.reduce(1)
+                self.buckets.finish()
+            check(L.gtg_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                  self.numel, ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps,
+                                  self.buckets.scale, stream), "gtg_adam_step")
+
+    def set_kl_weight(self, kl_w: float):
+        self.kl_w_dev.fill_(float(kl_w))
+
+    def run_loaded(self, update: bool = True, use_graph: bool = False):
+        """One step on the batch already in the static buffers."""
+        B = self._B
+        if use_graph and self.world == 1:
+            key = (B, update, self.ei.shape[1])
+            if self._graph is None or self._graph_key != key:
+                # warm up outside capture, then capture the whole step as one HIP graph
+                side = torch.cuda.Stream(device=self.dev)
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                snap = (self.flat_p.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
+                with torch.cuda.stream(side):
+                    self._launch(B, update, side.cuda_stream)
+                torch.cuda.current_stream(self.dev).wait_stream(side)
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._launch(B, update, torch.cuda.current_stream(self.dev).cuda_stream)
+                # the warm-up run advanced the optimiser once: roll it back
+                self.flat_p.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
+                self.adam_state.copy_(snap[3])
+                self._graph_key = key
+            self._graph.replay()
+        else:
+            self._launch(B, update, torch.cuda.current_stream(self.dev).cuda_stream)
+        return {"recon": self.scalars[0], "kl": self.scalars[1]}
+
+    def step(self, batch: GraphBatch, eps: torch.Tensor, kl_w: float = 1.0, update: bool = True,
+             use_graph: bool = False):
+        """Forward + backward (+ all-reduce + Adam when ``update``) on one batch.
+        Returns device scalars {"recon", "kl"}; ``last_out`` holds the decoder
+        probabilities (B, M) of this step."""
+        self.set_kl_weight(kl_w)
+        self.load_batch(batch, eps)
+        res = self.run_loaded(update, use_graph)
+        self.last_out = self.out[: self._B]
+        return res
+
+    def edges_ok(self) -> bool:
+        """Host read-back of the adjacency kernel's error flag (a sync)."""
+        return int(self.err.item()) == 0

@@ -1,0 +1,159 @@
+/* gtgvae.h — C ABI of libgtgvae_hip.so: the graph-VAE training hot path of
+ * gtg-vae as hand-written HIP kernels for AMD MI355X (gfx950 / CDNA4).
+ *
+ * The reference (/root/reference, pure Python) has no FFI of its own; its
+ * boundary is the Python class surface.  Each entry point below therefore
+ * cites the reference function whose arithmetic it replaces, and
+ * the Python modules under gtg-vae_amd/ mirror the reference's classes on top of this ABI.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller (inputs, outputs and
+ *     workspaces); the library allocates, frees and synchronises nothing;
+ *   - `stream` is a hipStream_t (NULL = the default stream); all kernels of a
+ *     call are launched on it in order, so calls can be captured in a HIP graph;
+ *   - dense matrices are row-major fp32; indices are int32 unless stated;
+ *   - return 0 on success, a negative GTG_ERR_* code otherwise, with a
+ *     human-readable message in gtg_last_error() (thread-local);
+ *   - n (nodes per padded graph) must be in [1, 64];
+ *   - *_workspace_bytes() return the exact size the matching call carves;
+ *     pass a buffer at least that large (256-byte aligned).
+ *   - all reductions are ordered: identical inputs give bit-identical outputs.
+ */
+#ifndef GTGVAE_H
+#define GTGVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTG_VERSION 1
+
+#define GTG_OK 0
+#define GTG_ERR_INVALID (-1)
+#define GTG_ERR_LAUNCH (-2)
+#define GTG_ERR_UNSUPPORTED (-3)
+#define GTG_ERR_WORKSPACE (-4)
+
+int gtg_version(void);
+const char* gtg_last_error(void);
+int gtg_max_nodes(void);
+
+/* ---- maximum-spanning-tree read-out ------------------------------------
+ * Replaces mst_graph / helper_mst / maximumSpanningTree / findMaxVertex /
+ * printMaximumSpanningTree (src/maxspantree.py:118-163, 61-115, 7-31, 35-58),
+ * one graph per 64-lane wavefront, bit-exact edge lists.
+ *   edges (G, n-1, 2) int32: ordered (parent, vertex) pairs, unused pairs = -1
+ *   count (G)        int32: number of pairs (V-1 for V present vertices, else 0)
+ * _triu takes rows (G, n(n+1)/2): the decoder's upper-triangular vectors; the
+ * symmetric matrix of GraphVAE.recover_adj_lower + recover_full_adj_from_lower
+ * (src/graph_vae.py:61-69) is formed on chip.  _full takes (G, n, n) matrices
+ * (row j / column m orientation of src/maxspantree.py:103-112 is kept). */
+int gtg_mst_batched_triu(const float* rows, int64_t num_graphs, int n, int32_t* edges, int32_t* count, void* stream);
+int gtg_mst_batched_full(const float* mats, int64_t num_graphs, int n, int32_t* edges, int32_t* count, void* stream);
+
+/* Replaces GraphVAE.graph_statistics (src/graph_vae.py:75-92) after the MST:
+ * gold_bits (G, n) uint64, bit b of word a set iff (a,b) is a gold edge.
+ * recall/precision (G) fp32; both 1 when the gold set or the prediction is empty. */
+int gtg_edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gold_bits, int64_t num_graphs, int n,
+                 float* recall, float* precision, void* stream);
+
+/* ---- normalised adjacency ----------------------------------------------
+ * Replaces the gcn_norm step inside torch_geometric GCNConv as called at
+ * src/graph_vae.py:107,110: self loops dropped, one unit self loop per node,
+ * in-degree with multiplicity, D^-1/2 (C + I) D^-1/2.
+ *   edge_index (2, E) int64, PyG batch numbering (node id = graph*n + local)
+ *   counts_ws (B*n*n) int32 scratch, err_flag (1) int32: set to 1 if an edge
+ *   leaves its graph or is out of range;  adj (B, n, n) fp32 output,
+ *   adj[b,i,j] = weight with which node j feeds node i. */
+int gtg_adj_build(const int64_t* edge_index, int64_t num_edges, int64_t num_graphs, int n, int32_t* counts_ws,
+                  int32_t* err_flag, float* adj, void* stream);
+
+/* ---- encoder -------------------------------------------------------------
+ * Replaces VGAE_encoder.forward (src/graph_vae.py:106-110: GCNConv, ReLU,
+ * GCNConv) + global_max_pool (src/graph_vae.py:25) and their backward.
+ *   x (B*n, f) node features, or NULL for stacked identities (then f == n,
+ *     src/train.py:203-204) — the X*W1^T GEMM is then skipped;
+ *   W1 (2d, f), b1 (2d), W2 (d, 2d), b2 (d)
+ *   h1 (B*n, 2d) saved activations; pooled (B, d); argmax (B, d) row index of
+ *   the pooled maximum (lowest row on ties). */
+size_t gtg_encoder_fwd_workspace_bytes(int64_t num_graphs, int n, int f, int d, int has_x);
+int gtg_encoder_fwd(const float* adj, const float* x, const float* W1, const float* b1, const float* W2,
+                    const float* b2, int64_t num_graphs, int n, int f, int d, float* h1, float* pooled,
+                    int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+size_t gtg_encoder_bwd_workspace_bytes(int64_t num_graphs, int n, int f, int d, int has_x);
+int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const float* W2, const float* h1,
+                    const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int f, int d, float* dW1,
+                    float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- latent head ---------------------------------------------------------
+ * Replaces zg_mu / zg_var (src/gtvae.py:25-26,108-109), reparameterize
+ * (src/gtvae.py:33-37, eps supplied by the caller) and loss_kl
+ * (src/gtvae.py:41-42).  kl (1) = -0.5 * sum(1 + logvar - mu^2 - e^logvar) / B.
+ * Backward: dz may be NULL (no reconstruction gradient); the KL term enters
+ * with weight kl_w * (*kl_w_dev if non-NULL). */
+size_t gtg_latent_workspace_bytes(int64_t num_graphs, int d);
+int gtg_latent_fwd(const float* h, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
+                   const float* eps, int64_t num_graphs, int d, float* mu, float* logvar, float* z, float* kl,
+                   void* ws, size_t ws_bytes, void* stream);
+int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const float* mu, const float* logvar,
+                   const float* eps, const float* dz, float kl_w, const float* kl_w_dev, int64_t num_graphs, int d,
+                   float* dWmu, float* dbmu, float* dWlv, float* dblv, float* dh, void* ws, size_t ws_bytes,
+                   void* stream);
+
+/* The element-wise half alone: GTVAE.reparameterize + GTVAE.loss_kl
+ * (src/gtvae.py:33-42) and their backward (dmu, dlogvar). */
+int gtg_reparam_kl_fwd(const float* mu, const float* logvar, const float* eps, int64_t num_graphs, int d, float* z,
+                       float* kl, void* ws, size_t ws_bytes, void* stream);
+int gtg_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, const float* dz, float kl_w,
+                       const float* kl_w_dev, int64_t num_graphs, int d, float* dmu, float* dlogvar, void* stream);
+
+/* ---- decoder + reconstruction loss ---------------------------------------
+ * gtg_decoder_fwd replaces MLP_VAE_plain.forward (src/graph_vae.py:126-131):
+ *   y1 (B, hid) = relu(z D1^T + c1), out (B, m_out) = sigmoid(y1 D2^T + c2).
+ * gtg_bce_loss_fwd replaces GraphVAE.loss + adj_recon_loss
+ * (src/graph_vae.py:34-59, 71-73): the mean over graphs of the mean over the
+ * n(n+1)/2 upper-triangular entries of BCE(out[b,k], adj_target[b,i,j]), log
+ * terms clamped at -100, no mask.  adj_target (B, n, n) fp32.
+ * gtg_bce_loss_bwd: gradient of that loss times gscale * (*gscale_dev if
+ * non-NULL), w.r.t. `out` (through_sigmoid = 0) or the logits (= 1).
+ * gtg_decoder_bwd: give either dout (gradient w.r.t. out) or adj_target (the
+ * BCE backward is then fused in and never materialised). */
+int gtg_decoder_fwd(const float* z, const float* D1, const float* c1, const float* D2, const float* c2,
+                    int64_t num_graphs, int d, int hid, int m_out, float* y1, float* out, void* stream);
+size_t gtg_bce_workspace_bytes(int64_t num_graphs);
+int gtg_bce_loss_fwd(const float* out, const float* adj_target, int64_t num_graphs, int n, float* loss, void* ws,
+                     size_t ws_bytes, void* stream);
+int gtg_bce_loss_bwd(const float* out, const float* adj_target, float gscale, const float* gscale_dev,
+                     int64_t num_graphs, int n, int through_sigmoid, float* grad, void* stream);
+size_t gtg_decoder_bwd_workspace_bytes(int64_t num_graphs, int d, int hid, int m_out);
+int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const float* y1, const float* out,
+                    const float* dout, const float* adj_target, int n, float gscale, const float* gscale_dev,
+                    int64_t num_graphs, int d, int hid, int m_out, float* dD1, float* dc1, float* dD2, float* dc2,
+                    float* dz, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- optimiser -------------------------------------------------------------
+ * Replaces optim.Adam(lr, betas=(0.5, 0.999)).step() (src/train.py:290,314)
+ * over one flat fp32 buffer.  state16: 16 device bytes, zero-initialised by the
+ * caller once; holds the step counter so that a captured HIP graph replays
+ * correctly.  grad_scale multiplies the gradient first (1/world_size after a
+ * sum all-reduce). */
+int gtg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, void* state16,
+                  float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* ---- the fp32 MFMA GEMM underneath (exposed for tests and profiling) -------
+ * C[M,N] = epilogue(op(A) op(B)); a_kc: A(m,k) at A[m*lda+k] else A[k*lda+m];
+ * b_kc: B(k,n) at B[n*ldb+k] else B[k*ldb+n].  epilogue: 0 store(+bias),
+ * 1 relu(+bias), 2 sigmoid(+bias), 3 mask by aux>0, 4 accumulate into C.
+ * slabs (optional) enables ordered split-K for short-and-wide shapes. */
+int gtg_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
+                 int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, void* slabs,
+                 size_t slab_bytes, void* stream);
+size_t gtg_gemm_splitk_workspace_bytes(int M, int N, int K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTGVAE_H */

@@ -1,0 +1,259 @@
+"""GPU parity of the graph-VAE hot path against the CPU oracle and the golden
+vectors: adjacency, encoder, latent head, decoder, BCE, full step gradients,
+Adam, determinism, HIP-graph replay.
+
+Tolerances (fp32 kernels): loss rel <= 1e-5, gradients max-abs-error /
+max-abs-value <= 1e-4, as stated for the fp32 path.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [(8, 10, 32, 64), (5, 32, 64, 96), (3, 64, 128, 512), (64, 10, 32, 512)]
+
+
+def _relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def _oracle_params(N, d, hid, seed=1, rand_bias=True):
+    from oracle import graphvae_oracle as O
+
+    p = O.init_params(N, d, hid, N, seed=seed)
+    if rand_bias:
+        g = torch.Generator().manual_seed(seed + 50)
+        p["encoder.conv1.bias"] = torch.randn(2 * d, generator=g) * 0.1
+        p["encoder.conv2.bias"] = torch.randn(d, generator=g) * 0.1
+    return p
+
+
+@pytest.mark.parametrize("B,N", [(4, 10), (7, 32), (5, 64), (3, 1)])
+def test_adj_build_matches_oracle(B, N):
+    from gtg_vae_amd import functional as Fn
+    from gtg_vae_amd.data import synth_graph_batch
+    from oracle import graphvae_oracle as O
+
+    if N == 1:
+        ei = torch.zeros((2, 3), dtype=torch.long)
+        ei[:, 1] = 1
+        ei[:, 2] = 2
+    else:
+        ei = synth_graph_batch(B, N, seed=B * N).edge_index
+    want = O.gcn_dense_adj(ei, B, N)
+    got = Fn.build_adj(ei.cuda(), B, N, check_edges=True)
+    assert torch.allclose(got.cpu(), want, rtol=1e-6, atol=1e-7)
+
+
+def test_adj_build_flags_cross_graph_edges():
+    from gtg_vae_amd import functional as Fn
+    from gtg_vae_amd._lib import GtgError
+
+    ei = torch.tensor([[0, 11], [1, 3]], dtype=torch.long).cuda()   # 11 -> 3 crosses graphs (N=10)
+    with pytest.raises(GtgError):
+        Fn.build_adj(ei, 2, 10, check_edges=True)
+
+
+@pytest.mark.parametrize("B,N,d,hid", CONFIGS)
+@pytest.mark.parametrize("identity_x", [True, False])
+def test_encoder_forward_backward(B, N, d, hid, identity_x):
+    from gtg_vae_amd import functional as Fn
+    from gtg_vae_amd.data import synth_graph_batch
+    from oracle import graphvae_oracle as O
+
+    batch = synth_graph_batch(B, N, seed=11)
+    p = {k: v.clone().requires_grad_(True) for k, v in _oracle_params(N, d, hid).items()}
+    x = None if identity_x else torch.randn(B * N, N, generator=torch.Generator().manual_seed(2))
+    want = O.encode(p, x, batch.edge_index, B, N)
+    up = torch.randn(B, d, generator=torch.Generator().manual_seed(3))
+    (want * up).sum().backward()
+
+    names = ["encoder.conv1.lin.weight", "encoder.conv1.bias", "encoder.conv2.lin.weight", "encoder.conv2.bias"]
+    gp = [p[k].detach().cuda().requires_grad_(True) for k in names]
+    adj = Fn.build_adj(batch.edge_index.cuda(), B, N)
+    got, argmax = Fn.EncoderFn.apply(adj, None if x is None else x.cuda(), *gp)
+    assert _relerr(got, want) < 1e-5
+    (got * up.cuda()).sum().backward()
+    for k, t in zip(names, gp):
+        assert _relerr(t.grad, p[k].grad) < 1e-4, k
+
+
+@pytest.mark.parametrize("B,d", [(8, 32), (256, 256), (5, 7)])
+def test_latent_forward_backward(B, d):
+    from gtg_vae_amd import functional as Fn
+    from oracle import graphvae_oracle as O
+
+    g = torch.Generator().manual_seed(B + d)
+    p = {k: v.clone().requires_grad_(True) for k, v in _oracle_params(10, d, 16).items() if k.startswith("zg_")}
+    h = torch.randn(B, d, generator=g).requires_grad_(True)
+    eps = torch.randn(B, d, generator=g)
+    z, mu, lv, kl = O.latent(p, h, eps)
+    up = torch.randn(B, d, generator=g)
+    ((z * up).sum() + 0.37 * kl).backward()
+
+    names = ["zg_mu.weight", "zg_mu.bias", "zg_var.weight", "zg_var.bias"]
+    gp = [p[k].detach().cuda().requires_grad_(True) for k in names]
+    hg = h.detach().cuda().requires_grad_(True)
+    gz, gkl, gmu, glv = Fn.LatentFn.apply(hg, *gp, eps.cuda())
+    assert _relerr(gz, z) < 1e-5 and _relerr(gmu, mu) < 1e-5 and _relerr(glv, lv) < 1e-5
+    assert abs(gkl.item() - kl.item()) <= 1e-5 * abs(kl.item())
+    ((gz * up.cuda()).sum() + 0.37 * gkl).backward()
+    assert _relerr(hg.grad, h.grad) < 1e-4
+    for k, t in zip(names, gp):
+        assert _relerr(t.grad, p[k].grad) < 1e-4, k
+    # stand-alone reparameterisation / KL
+    mu2 = mu.detach().cuda().requires_grad_(True)
+    lv2 = lv.detach().cuda().requires_grad_(True)
+    z2, kl2 = Fn.ReparamKLFn.apply(mu2, lv2, eps.cuda())
+    assert _relerr(z2, z) < 1e-5 and abs(kl2.item() - kl.item()) <= 1e-5 * abs(kl.item())
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_decoder_and_bce_match_reference_golden(golden_dir, tag):
+    """Against values produced by the reference's own MLP_VAE_plain / adj_recon_loss."""
+    from gtg_vae_amd import functional as Fn
+
+    g = np.load(os.path.join(golden_dir, "graphvae_golden.npz"))
+    names = ["decode_1.weight", "decode_1.bias", "decode_2.weight", "decode_2.bias"]
+    gp = [torch.from_numpy(g[f"{tag}__dec__{k}"]).cuda().requires_grad_(True) for k in names]
+    z = torch.from_numpy(g[f"{tag}__z"]).cuda().requires_grad_(True)
+    out = Fn.DecoderFn.apply(z, *gp)
+    assert torch.allclose(out.cpu(), torch.from_numpy(g[f"{tag}__out"]), rtol=1e-5, atol=1e-6)
+    adj = torch.from_numpy(g[f"{tag}__adj"]).cuda()
+    loss = Fn.BCELossFn.apply(out, adj)
+    assert loss.item() == pytest.approx(float(g[f"{tag}__bce_mean"]), rel=1e-5)
+    loss.backward()
+    assert _relerr(z.grad, torch.from_numpy(g[f"{tag}__dz"])) < 1e-4
+    for k, t in zip(names, gp):
+        assert _relerr(t.grad, torch.from_numpy(g[f"{tag}__grad__{k}"])) < 1e-4, k
+
+
+def test_bce_clamp_at_the_ends(golden_dir):
+    from gtg_vae_amd import functional as Fn
+
+    # n = 1: M = 1, one probability per "graph"
+    g = np.load(os.path.join(golden_dir, "graphvae_golden.npz"))
+    p, t, each = g["edge__p"], g["edge__t"], g["edge__bce_each"]
+    out = torch.from_numpy(p).reshape(-1, 1).cuda()
+    adj = torch.from_numpy(t).reshape(-1, 1, 1).cuda()
+    loss = Fn.BCELossFn.apply(out, adj)
+    assert loss.item() == pytest.approx(float(each.astype(np.float64).mean()), rel=1e-6)
+
+
+@pytest.mark.parametrize("B,N,d,hid", CONFIGS)
+def test_module_step_matches_oracle(B, N, d, hid):
+    """GTVAE(text=False).forward/backward through autograd == oracle."""
+    from gtg_vae_amd import GTVAE
+    from gtg_vae_amd.data import synth_graph_batch
+    from oracle import graphvae_oracle as O
+
+    batch = synth_graph_batch(B, N, seed=21)
+    params = _oracle_params(N, d, hid, seed=4)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(8))
+    kl_w = 0.3
+    loss, rec, kl, out = O.graph_step_loss(p, None, batch.edge_index, batch.adj_padded, eps, kl_w, B, N)
+    loss.backward()
+
+    model = GTVAE(N, d, hid, N, text=False).cuda()
+    sd = {("graph_vae." + k if not k.startswith("zg_") else k): v for k, v in params.items()}
+    model.load_state_dict(sd)
+    gb = batch.to("cuda")
+    res = model(gb.dense_x(), gb.edge_index, gb.batch, gb.adj_padded, gb.gold_edges, None, kl_w, eps=eps.cuda())
+    gloss, _, gkl, grec = res[0], res[1], res[2], res[3]
+    assert abs(gloss.item() - loss.item()) <= 1e-5 * abs(loss.item())
+    assert abs(grec.item() - rec.item()) <= 1e-5 * abs(rec.item())
+    assert abs(gkl.item() - kl.item()) <= 1e-5 * abs(kl.item())
+    gloss.backward()
+    got = dict(model.named_parameters())
+    for k, v in p.items():
+        key = "graph_vae." + k if not k.startswith("zg_") else k
+        assert _relerr(got[key].grad, v.grad) < 1e-4, k
+
+
+@pytest.mark.parametrize("B,N,d,hid", CONFIGS)
+def test_trainer_step_and_adam_match_oracle(B, N, d, hid):
+    from gtg_vae_amd.data import synth_graph_batch
+    from gtg_vae_amd.trainer import GraphVAETrainer
+    from oracle import graphvae_oracle as O
+
+    params = _oracle_params(N, d, hid, seed=6)
+    tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    for step in range(1, 4):
+        batch = synth_graph_batch(B, N, seed=30 + step)
+        eps = torch.randn(B, d, generator=torch.Generator().manual_seed(step))
+        kl_w = 0.1 * step
+        for t in p.values():
+            t.grad = None
+        loss, rec, kl, _ = O.graph_step_loss(p, None, batch.edge_index, batch.adj_padded, eps, kl_w, B, N)
+        loss.backward()
+        res = tr.step(batch.to("cuda"), eps.cuda(), kl_w=kl_w, update=True)
+        assert tr.edges_ok()
+        assert abs(res["recon"].item() - rec.item()) <= 1e-5 * abs(rec.item())
+        assert abs(res["kl"].item() - kl.item()) <= 1e-5 * abs(kl.item()) + 1e-7
+        for k in p:
+            assert _relerr(tr.named_grads()[k], p[k].grad) < 1e-4, (step, k)
+        with torch.no_grad():
+            for k in p:
+                O.adam_step(p[k], p[k].grad, m[k], v2[k], step)
+        for k in p:
+            # Adam normalises the step to ~lr per element, so compare parameters absolutely
+            assert (tr.named_params()[k].cpu() - p[k].detach()).abs().max().item() < 2e-5, (step, k)
+
+
+def test_step_is_bitwise_deterministic_and_graph_replay_matches():
+    from gtg_vae_amd.data import synth_graph_batch
+    from gtg_vae_amd.trainer import GraphVAETrainer
+
+    B, N, d, hid = 32, 32, 64, 128
+    params = _oracle_params(N, d, hid, seed=9)
+    batch = synth_graph_batch(B, N, seed=77).to("cuda")
+    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(5)).cuda()
+    runs = []
+    for use_graph in (False, False, True):
+        tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params)
+        for _ in range(3):
+            res = tr.step(batch, eps, kl_w=0.5, update=True, use_graph=use_graph)
+        torch.cuda.synchronize()
+        runs.append((tr.flat_p.clone(), tr.flat_g.clone(), res["recon"].item(), res["kl"].item()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert torch.equal(runs[0][0], runs[2][0]) and torch.equal(runs[0][1], runs[2][1])
+    assert runs[0][2:] == runs[1][2:] == runs[2][2:]
+
+
+def test_loss_report_precision_recall_matches_oracle():
+    from gtg_vae_amd import GraphVAE
+    from gtg_vae_amd.data import synth_graph_batch
+    from oracle import mst_oracle
+
+    B, N = 24, 10
+    batch = synth_graph_batch(B, N, seed=3)
+    model = GraphVAE(N, 32, 64, N, 1).cuda()
+    out = torch.rand(B, N * (N + 1) // 2, generator=torch.Generator().manual_seed(1)).cuda()
+    _, rec, prec = model.loss(out, batch.adj_padded.numpy(), batch.gold_edges, True)
+    r32, p32 = np.float32(0), np.float32(0)
+    for b in range(B):
+        edges = mst_oracle.mst_edges_from_triu(out[b].cpu().numpy(), N)
+        r, p = mst_oracle.edge_precision_recall(edges, batch.gold_edges[b])
+        r32 = np.float32(r32 + np.float32(r))
+        p32 = np.float32(p32 + np.float32(p))
+    assert rec.item() == float(np.float32(r32) / np.float32(B))
+    assert prec.item() == float(np.float32(p32) / np.float32(B))
+    # report=False returns exact zeros like the reference
+    _, r0, p0 = model.loss(out, batch.adj_padded.numpy(), batch.gold_edges, False)
+    assert r0.item() == 0.0 and p0.item() == 0.0
+
+
+def test_cpu_tensors_fail_loudly():
+    from gtg_vae_amd import functional as Fn
+    from gtg_vae_amd._lib import GtgError
+
+    with pytest.raises(GtgError):
+        Fn.build_adj(torch.zeros((2, 1), dtype=torch.long), 1, 4)

@@ -1,0 +1,125 @@
+"""GPU parity of the batched MST kernel: bit-exact edge lists against the
+reference's own outputs (golden vectors) and against the C oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "mst_golden.npz"))
+
+
+def _run_full(G):
+    from gtg_vae_amd import mst_graph_batched
+
+    e, c = mst_graph_batched(torch.from_numpy(np.ascontiguousarray(G)).cuda())
+    return e.cpu().numpy(), c.cpu().numpy()
+
+
+def test_golden_full_matrices_bit_exact(gold):
+    from gtg_vae_amd import mst_graph
+
+    for name in gold["names"]:
+        G = gold[f"G__{name}"]
+        want = gold[f"E__{name}"]
+        e, c = _run_full(G[None])
+        assert int(c[0]) == len(want), name
+        assert np.array_equal(e[0, : len(want)], want), name
+        assert np.all(e[0, len(want):] == -1), name
+    # the reference-signature entry point returns a python list of tuples
+    G = gold["G__doc_sample"]
+    assert mst_graph(torch.from_numpy(G)) == [(2, 4)]
+
+
+def test_golden_triu_rows_bit_exact(gold):
+    from gtg_vae_amd import mst_graph_batched
+
+    for name in gold["triu_names"]:
+        row = gold[f"R__{name}"]
+        want = gold[f"E__{name}"]
+        e, c = mst_graph_batched(torch.from_numpy(row[None].copy()).cuda())
+        e, c = e.cpu().numpy(), c.cpu().numpy()
+        assert int(c[0]) == len(want) and np.array_equal(e[0, : len(want)], want), name
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 10, 31, 32, 33, 64])
+def test_random_batches_match_c_oracle(n):
+    from oracle import c_mst
+    from gtg_vae_amd import mst_graph_batched
+
+    rng = np.random.default_rng(100 + n)
+    G = 777
+    m = n * (n + 1) // 2
+    rows = rng.uniform(0, 1, size=(G, m)).astype(np.float32)
+    rows[rng.uniform(size=rows.shape) < 0.2] = 0.0          # disconnected pieces
+    rows[: G // 3] = np.round(rows[: G // 3] * 8) / 8        # ties
+    iu = np.triu_indices(n)
+    diag_pos = np.nonzero(iu[0] == iu[1])[0]
+    rows[:, diag_pos] = rng.uniform(0.3, 1.0, size=(G, n)).astype(np.float32)
+    we, wc = c_mst.mst_triu(rows, n)
+    e, c = mst_graph_batched(torch.from_numpy(rows).cuda(), n)
+    assert np.array_equal(c.cpu().numpy(), wc)
+    assert np.array_equal(e.cpu().numpy(), we)
+    # full-matrix entry, non-symmetric input
+    mats = rng.uniform(0, 1, size=(G, n, n)).astype(np.float32)
+    mats[rng.uniform(size=mats.shape) < 0.3] = 0.0
+    mats[:, np.arange(n), np.arange(n)] = rng.uniform(0.3, 1.0, size=(G, n)).astype(np.float32)
+    we, wc = c_mst.mst_full(mats)
+    e, c = _run_full(mats)
+    assert np.array_equal(c, wc) and np.array_equal(e, we)
+
+
+def test_extreme_values_match_oracle():
+    from oracle import c_mst
+
+    rng = np.random.default_rng(9)
+    specials = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, -1e19, -9.3e18, 1e-45, 0.5, 0.25], dtype=np.float32)
+    n, G = 12, 512
+    mats = rng.uniform(-1, 1, size=(G, n, n)).astype(np.float32)
+    mask = rng.uniform(size=mats.shape) < 0.35
+    mats[mask] = rng.choice(specials, size=int(mask.sum()))
+    mats[:, np.arange(n), np.arange(n)] = rng.uniform(0.2, 1.0, size=(G, n)).astype(np.float32)
+    we, wc = c_mst.mst_full(mats)
+    e, c = _run_full(mats)
+    assert np.array_equal(c, wc) and np.array_equal(e, we)
+
+
+def test_config_d_size_properties():
+    """65 536 graphs at N=64 (the batched read-out configuration): checked through
+    size-independent properties, and a 2 048-graph sample against the oracle."""
+    from oracle import c_mst
+    from gtg_vae_amd import mst_graph_batched
+
+    n, G = 64, 65536
+    m = n * (n + 1) // 2
+    g = torch.Generator(device="cpu").manual_seed(99)
+    rows = torch.rand((G, m), generator=g)
+    iu = torch.triu_indices(n, n)
+    dpos = torch.nonzero(iu[0] == iu[1]).flatten()
+    rows[:, dpos] = 0.3 + 0.7 * torch.rand((G, n), generator=g)
+    d_rows = rows.cuda()
+    e, c = mst_graph_batched(d_rows, n)
+    e2, c2 = mst_graph_batched(d_rows, n)
+    assert torch.equal(e, e2) and torch.equal(c, c2)            # deterministic
+    present = (rows[:, dpos] > 0.5)
+    V = present.sum(dim=1).to(torch.int32)
+    assert torch.equal(c.cpu(), torch.clamp(V - 1, min=0))       # V-1 edges
+    ec = e.cpu()
+    valid = torch.arange(n - 1)[None, :] < c.cpu()[:, None]
+    child = ec[:, :, 1]
+    parent = ec[:, :, 0]
+    assert bool((ec[~valid] == -1).all())
+    # children are exactly the present vertices except the first, ascending; parents are present
+    for b in range(0, G, 4099):
+        pres = torch.nonzero(present[b]).flatten().tolist()
+        k = int(c[b])
+        assert child[b, :k].tolist() == pres[1:]
+        assert set(parent[b, :k].tolist()) <= set(pres)
+    sample = slice(0, 2048)
+    we, wc = c_mst.mst_triu(rows[sample].numpy(), n)
+    assert np.array_equal(ec[sample].numpy(), we) and np.array_equal(c.cpu().numpy()[sample], wc)
