@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the graph-VAE training hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One step = one full training pass over one synthetic batch: adjacency build,
+GCN encoder + max-pool, latent head + reparameterisation + KL, MLP decoder,
+upper-triangular BCE, the complete backward pass, (all-reduce), Adam.  Inputs
+are resident in HBM before the timed region.  Workload = BASELINE.json
+configs[2]: N=64 nodes, batch 512 PER GPU (weak scaling), d=512, mlp_hid=512,
+fp32.  For N>1 launch with torch.distributed.run (one rank per GPU, RCCL).
+
+Prints ONE JSON line (rank 0) with the headline metric, the roofline of the
+dominant kernel (fp32 MFMA GEMM, timed with HIP events inside the timed
+region) and, at N=1, the CPU baseline (the build-owned PyTorch-CPU oracle of
+the same step, timed on this host's cores) plus the batched-MST read-out figure.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
+PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E peak
+
+
+def flops_per_graph_fwd(N, d, h):
+    M = N * (N + 1) // 2
+    return 4 * N * N * d + 4 * N * d * d + 2 * N * N * d + 4 * d * d + 2 * d * h + 2 * h * M
+
+
+def cpu_baseline(N, B, d, hid, budget_s=20.0):
+    """The oracle's training step (scatter GCN as PyG does it, autograd, Adam)
+    on the host cores: >=3 warm-up steps, then timed steps until the budget."""
+    from gtg_vae_amd.data import synth_graph_batch
+    from oracle import graphvae_oracle as O
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    params = {k: v.clone().requires_grad_(True) for k, v in O.init_params(N, d, hid, N, seed=0).items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3, betas=(0.5, 0.999))
+    batches = [synth_graph_batch(B, N, seed=1234 + i) for i in range(2)]
+    g = torch.Generator().manual_seed(1)
+    times = []
+    t_start = time.perf_counter()
+    i = 0
+    while True:
+        b = batches[i % 2]
+        eps = torch.randn(B, d, generator=g)
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss, _, _, _ = O.graph_step_loss(params, None, b.edge_index, b.adj_padded, eps, 0.5, B, N)
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        i += 1
+        if i > 3:
+            times.append(dt)
+        if (i >= 6 and time.perf_counter() - t_start > budget_s) or i >= 40:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "graphs/s", "cores": threads, "kind": "port",
+            "sample": "%d timed steps of the same workload (B=%d, N=%d, d=%d), median step %.1f ms; oracle = eager "
+                      "PyTorch-CPU scatter-GCN step with autograd + Adam" % (len(times), B, N, d, med * 1e3)}
+
+
+def mst_bench(device, G=65536, N=64, reps=5):
+    """BASELINE.json configs[3]: 65 536 decoder rows (N=64) -> spanning trees."""
+    from gtg_vae_amd import _lib, mst_graph_batched
+
+    M = N * (N + 1) // 2
+    g = torch.Generator().manual_seed(99)
+    rows = torch.rand((G, M), generator=g)
+    iu = torch.triu_indices(N, N)
+    dpos = torch.nonzero(iu[0] == iu[1]).flatten()
+    rows[:, dpos] = 0.3 + 0.7 * torch.rand((G, N), generator=g)
+    rows = rows.to(device)
+    mst_graph_batched(rows, N)
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for _ in range(reps):
+        mst_graph_batched(rows, N)
+    torch.cuda.synchronize()
+    rep = [r for r in _lib.profile_report() if r[0] == "mst_triu"]
+    _lib.profile_enable(False)
+    ms = rep[0][5] / rep[0][4]
+    bytes_per_graph = 4 * M + 4 * (2 * (N - 1) + 1)
+    gbps = G * bytes_per_graph / (ms * 1e-3) / 1e9
+    return {"workload": "configs[3]: %d graphs, N=%d, upper-triangular fp32 rows" % (G, N),
+            "graphs_per_s": G / (ms * 1e-3), "ms": ms,
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": gbps / PEAK_HBM_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_graph": bytes_per_graph}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--nodes", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=512, help="graphs per GPU per step")
+    ap.add_argument("--latent", type=int, default=512)
+    ap.add_argument("--hid", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mst", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (N=1 only; no per-kernel timing)")
+    args = ap.parse_args()
+
+    from gtg_vae_amd import _lib
+    from gtg_vae_amd.data import synth_graph_batch
+    from gtg_vae_amd.parallel import init_process_group
+    from gtg_vae_amd.trainer import GraphVAETrainer
+
+    rank, local_rank, world = init_process_group()
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    N, B, d, hid = args.nodes, args.batch, args.latent, args.hid
+
+    # identical initial weights on every rank, different data per rank
+    tr = GraphVAETrainer(N, d, hid, N, device=dev, seed=0, max_batch=B, max_edges=B * N * 4)
+    nb = 4
+    batches = [synth_graph_batch(B, N, seed=1234 + rank * 1000 + i).to(dev) for i in range(nb)]
+    gen = torch.Generator().manual_seed(4321 + rank)
+    eps = [torch.randn(B, d, generator=gen).to(dev) for _ in range(nb)]
+    tr.set_kl_weight(0.5)
+    use_graph = args.graph and world == 1
+
+    def one_step(i):
+        tr.load_batch(batches[i % nb], eps[i % nb])
+        tr.run_loaded(update=True, use_graph=use_graph)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not use_graph:
+        _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_report() if not use_graph else []
+    _lib.profile_enable(False)
+    if not tr.edges_ok():
+        raise SystemExit("adjacency kernel flagged an invalid edge list")
+    recon, kl = tr.scalars[0].item(), tr.scalars[1].item()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        F = flops_per_graph_fwd(N, d, hid)
+        # dominant kernel: the 128x128-tile fp32 MFMA GEMM launch with the largest total time
+        roof = None
+        kern = {}
+        big = [r for r in prof if r[0].startswith("gemm")]
+        if big:
+            top = max(big, key=lambda r: r[5])
+            name, m_, n_, k_, cnt, tot_ms = top
+            fl = 2.0 * m_ * n_ * k_
+            avg_ms = tot_ms / cnt
+            ach = fl / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": name,
+                    "launch": {"M": m_, "N": n_, "K": k_, "flops": fl, "avg_ms": avg_ms, "launches": cnt}}
+            for r in sorted(big, key=lambda r: -r[5])[:8]:
+                kern["%s M%d N%d K%d" % r[:4]] = {"avg_ms": r[5] / r[4], "tflops": 2.0 * r[1] * r[2] * r[3] / (r[5] / r[4] * 1e-3) / 1e12}
+        step_tflops = value * 3 * F / 1e12
+        line = {
+            "metric": "training graphs/sec (whole node) at N=64 nodes, batch 512; 1/2/4/8 MI355X",
+            "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: synthetic AMR-shaped graphs N<=%d (padded to %d), batch %d per GPU, "
+                                   "latent d=%d, mlp_hid=%d, graph-only step: recon + kl_w*KL, full backward, Adam" % (N, N, B, d, hid),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "hip_graph": bool(use_graph)},
+            "step_algorithmic_tflops": step_tflops,
+            "step_frac_of_f32_mfma_peak": step_tflops / (PEAK_F32_MFMA_TFLOPS * world),
+            "loss": {"recon": recon, "kl": kl},
+            "roofline": roof,
+            "gemm_kernels": kern,
+        }
+        if world == 1 and not args.no_mst:
+            line["mst"] = mst_bench(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(N, B, d, hid)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,8 @@ _SIGS = {
     "gtg_version": (c_int, []),
     "gtg_last_error": (ctypes.c_char_p, []),
     "gtg_max_nodes": (c_int, []),
+    "gtg_profile_enable": (c_int, [c_int]),
+    "gtg_profile_report": (c_int64, [ctypes.c_char_p, c_size_t]),
     "gtg_mst_batched_triu": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "gtg_mst_batched_full": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "gtg_edge_prf": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P]),
@@ -66,6 +68,21 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+def profile_enable(on: bool) -> None:
+    lib().gtg_profile_enable(int(on))
+
+
+def profile_report():
+    """[(kernel, dim0, dim1, dim2, count, total_ms)] since profiling was enabled; clears the records."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib().gtg_profile_report(buf, len(buf))
+    rows = []
+    for line in buf.value.decode().splitlines():
+        k, a, b, c, n, ms = line.split()
+        rows.append((k, int(a), int(b), int(c), int(n), float(ms)))
+    return rows
 
 
 def check(rc: int, what: str = "") -> None:

@@ -10,6 +10,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "../../include/gtgvae.h"
 #include "gtg_internal.h"
 
@@ -31,6 +36,40 @@ int check_launch(const char* what)
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GTG_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return GTG_OK;
+}
+
+// ---- per-launch timing ------------------------------------------------------
+struct ProfRec {
+    hipEvent_t a, b;
+    std::string tag;
+};
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
+static bool g_prof_on = false;
+
+ProfScope::ProfScope(hipStream_t s, const char* tag, long long a, long long b, long long c) : stream(s)
+{
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    if (hipEventCreate(&r.a) != hipSuccess) return;
+    if (hipEventCreate(&r.b) != hipSuccess) {
+        (void)hipEventDestroy(r.a);
+        return;
+    }
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%s %lld %lld %lld", tag, a, b, c);
+    r.tag = buf;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+
+ProfScope::~ProfScope()
+{
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].b, stream);
 }
 
 namespace {
@@ -83,6 +122,51 @@ int gtg_version(void) { return GTG_VERSION; }
 const char* gtg_last_error(void) { return g_err; }
 
 int gtg_max_nodes(void) { return 64; }
+
+// Timing of the GEMM and MST launches with HIP events on the caller's stream.
+// Not for use under graph capture.  gtg_profile_report writes one line per
+// distinct launch, "<tag> <dim0> <dim1> <dim2> <count> <total_ms>", returns the
+// number of bytes written (or needed), and clears the records.
+int gtg_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return GTG_OK;
+}
+
+int64_t gtg_profile_report(char* buf, size_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::map<std::string, std::pair<long long, double>> agg;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto& e = agg[r.tag];
+            e.first += 1;
+            e.second += ms;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    std::string out;
+    for (auto& kv : agg) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s %lld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    if (buf && cap > 0) {
+        const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)out.size();
+}
 
 // ---------------------------------------------------------------------------
 // MST read-out and edge statistics

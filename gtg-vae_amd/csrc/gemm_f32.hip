@@ -425,6 +425,12 @@ int gemm(const GemmDesc& d, hipStream_t s)
     const long long grid = (long long)k.tiles_m * k.tiles_n * splits * d.batch;
     if (grid > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "gemm: grid too large");
 
+    static const char* const kNames[3][3] = {
+        {"gemm128_nt", "gemm128_nn", "gemm128_tn"},
+        {"gemm64x128_nt", "gemm64x128_nn", "gemm64x128_tn"},
+        {"gemm64_nt", "gemm64_nn", "gemm64_tn"}};
+    const int lay = d.a_kc ? (d.b_kc ? 0 : 1) : 2;
+    ProfScope prof(s, kNames[(int)cfg][lay], (long long)d.M * d.batch, d.N, d.K);
     int rc;
     switch (cfg) {
         case CFG_128: rc = launch_cfg<128, 128, 2>(k, d.a_kc, d.b_kc, (int)grid, s); break;

@@ -12,6 +12,17 @@ namespace gtg {
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
 
+// ---- optional per-launch timing (off by default) -----------------------------
+// When enabled through gtg_profile_enable(1), selected launch sites bracket
+// their kernel with a pair of HIP events on the caller's stream;
+// gtg_profile_report() synchronises them and aggregates by tag.
+struct ProfScope {
+    int slot = -1;
+    hipStream_t stream;
+    ProfScope(hipStream_t s, const char* tag, long long a, long long b, long long c);
+    ~ProfScope();
+};
+
 // ---- fp32 MFMA GEMM ---------------------------------------------------------
 // C[M,N] (+)= op(A)[M,K] * op(B)[K,N], fp32 in / fp32 accumulate on
 // v_mfma_f32_32x32x2_f32.  Operand layouts:

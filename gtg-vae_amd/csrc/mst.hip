@@ -176,6 +176,7 @@ static int mst_launch(bool triu, const float* in, int64_t G, int n, int32_t* edg
     if (!in || !count || (n > 1 && !edges)) return set_error(GTG_ERR_INVALID, "mst: null pointer");
     const int64_t blocks = (G + WAVES - 1) / WAVES;
     if (blocks > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "mst: too many graphs for one launch");
+    ProfScope prof(s, triu ? "mst_triu" : "mst_full", G, n, 0);
     if (triu)
         hipLaunchKernelGGL(mst_kernel<true>, dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
     else

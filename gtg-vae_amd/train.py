@@ -1,0 +1,148 @@
+"""Training / evaluation loop with the reference's structure and printed fields.
+
+Mirrors ``train()`` and ``dev()`` of /root/reference/src/train.py:284-355 and
+:228-282: Adam(lr=1e-3, betas=(0.5, 0.999)), KL weight annealed per EPOCH as
+min(epoch / 500, 1) (train.py:294), batch-size-weighted epoch means, the same
+printed lines (train.py:343-352, 273-279), a dev pass after every epoch.  The
+step itself is GraphVAETrainer's fused HIP path; with several ranks
+(torchrun) every rank trains on its own shard of each batch and gradients are
+all-reduced over RCCL.
+
+    python -m gtg_vae_amd.train --synthetic 4096 --nodes 10 --batch 64 --latent 32 --epochs 3
+    python -m gtg_vae_amd.train --train amr.mrp --dev dev.mrp --nodes 10
+"""
+import argparse
+import time
+
+import torch
+
+from .data import DataLoader, load_mrp, prep_data_list, synth_graph_list
+from .parallel import all_reduce_scalars, init_process_group, shard_range
+from .trainer import GraphVAETrainer
+
+NKL = 500  # epochs over which the KL weight ramps to 1 (train.py:286,294)
+
+
+def dev(loader, trainer: GraphVAETrainer, epoch, kl_anneal_w, generator=None, quiet=False):
+    sums = torch.zeros(5, dtype=torch.float64)
+    n_inst = 0
+    for batch in loader:
+        B = batch.num_graphs
+        eps = torch.randn(B, trainer.d, generator=generator).to(trainer.dev)
+        res = trainer.evaluate(batch.to(trainer.dev), eps, report=True)
+        vals = torch.stack([res["recon"] + kl_anneal_w * res["kl"], res["recon"], res["kl"], res["edge_recall"],
+                            res["edge_precision"]]).double().cpu()
+        sums += vals * B
+        n_inst += B
+    means = (sums / max(n_inst, 1)).tolist()
+    if not quiet:
+        print("DEV")
+        print("Epoch: {}".format(epoch))
+        print("Epoch loss: {:.3f}".format(means[0]))
+        print("Epoch graph_recon loss: {:.3f}".format(means[1]), "Epoch text_recon_loss: {:.3f}".format(0.0))
+        print("Epoch joint_kl_loss: {:.3f}".format(means[2]))
+        print("Epoch edge_recall: {:.3f}".format(means[3]), "Epoch edge_precision: {:.3f}".format(means[4]))
+        print("Epoch text_acc: {:.3f}".format(0.0))
+    return dict(zip(("loss", "graph_recon", "kl", "edge_recall", "edge_precision"), means))
+
+
+def train(train_loader, dev_loader, trainer: GraphVAETrainer, epochs, model_name="gtg", rank=0, world=1,
+          generator=None, use_graph=False, quiet=False, save_every=0):
+    lr = trainer.lr
+    if rank == 0 and not quiet:
+        print("trnsize: {}, devsize: {}, num_epochs: {}, nkl: {}, at: {}, lr: {}".format(
+            len(train_loader.dataset), len(dev_loader.dataset) if dev_loader else 0, epochs, NKL, 0.3, lr))
+    history = []
+    for epoch in range(epochs):
+        kl_anneal_w = min(epoch / NKL, 1)
+        trainer.set_kl_weight(kl_anneal_w)
+        sums = torch.zeros(3, dtype=torch.float64, device=trainer.dev)
+        n_inst = 0
+        t0 = time.perf_counter()
+        for batch in train_loader:
+            if world > 1:
+                lo, hi = shard_range(batch.num_graphs, rank, world)
+                batch = slice_batch(batch, lo, hi)
+            B = batch.num_graphs
+            eps = torch.randn(B, trainer.d, generator=generator).to(trainer.dev)
+            trainer.load_batch(batch.to(trainer.dev), eps)
+            res = trainer.run_loaded(update=True, use_graph=use_graph)
+            # device-side accumulation: no host sync inside the epoch (the reference syncs with loss.item(), train.py:316)
+            sums += torch.stack([res["recon"] + kl_anneal_w * res["kl"], res["recon"], res["kl"]]).double() * B
+            n_inst += B
+        torch.cuda.synchronize(trainer.dev)
+        dt = time.perf_counter() - t0
+        tot = torch.cat([sums, torch.tensor([float(n_inst)], dtype=torch.float64, device=trainer.dev)])
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(tot)
+        means = (tot[:3] / tot[3]).tolist()
+        history.append({"epoch": epoch, "loss": means[0], "graph_recon": means[1], "kl": means[2],
+                        "graphs_per_s": tot[3].item() / dt})
+        if rank == 0 and not quiet:
+            print("\n ============================")
+            print("Epoch: {}".format(epoch))
+            print("Epoch loss: {:.3f}".format(means[0]))
+            print("Epoch graph_recon loss: {:.3f}".format(means[1]), "Epoch text_recon_loss: {:.3f}".format(0.0))
+            print("Epoch joint_kl_loss: {:.3f}".format(means[2]))
+            print("kl_anneal_w:", kl_anneal_w)
+            print("graphs/s: {:.0f}".format(tot[3].item() / dt))
+        if dev_loader is not None and rank == 0:
+            history[-1]["dev"] = dev(dev_loader, trainer, epoch, kl_anneal_w, generator, quiet)
+        if save_every and rank == 0 and epoch % save_every == 0:
+            torch.save(trainer.state_dict(), "%s_%d" % (model_name, epoch))  # cadence of train.py:356-358
+    return history
+
+
+def slice_batch(batch, lo, hi):
+    """Graphs [lo, hi) of a collated batch (host tensors), renumbered from 0."""
+    from .data import GraphBatch
+
+    n = batch.nmax
+    ei = batch.edge_index
+    g = ei[1] // n
+    keep = (g >= lo) & (g < hi)
+    ei = (ei[:, keep] - lo * n).contiguous()
+    B = hi - lo
+    return GraphBatch(ei, batch.batch[: B * n].clone(), batch.adj_padded[lo:hi].contiguous(), batch.gold_edges[lo:hi],
+                      batch.snts[lo:hi], B, n, batch.num_nodes[lo:hi], None, batch.gold_bits[lo:hi].contiguous())
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--train", help="MRP JSON-lines file (nodes / edges[{source,target}] / input)")
+    ap.add_argument("--dev")
+    ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic AMR-shaped training graphs")
+    ap.add_argument("--nodes", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--latent", type=int, default=32)
+    ap.add_argument("--hid", type=int, default=512)
+    ap.add_argument("--epochs", type=int, default=521)
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--hip-graph", action="store_true")
+    ap.add_argument("--save-every", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    rank, local_rank, world = init_process_group()
+    dev_ = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_)
+    if args.train:
+        trn = prep_data_list(load_mrp(args.train), args.nodes)
+        val = prep_data_list(load_mrp(args.dev), args.nodes) if args.dev else []
+    else:
+        n = args.synthetic or 4096
+        trn = synth_graph_list(n, args.nodes, seed=1234)
+        val = synth_graph_list(max(n // 8, args.batch), args.nodes, seed=4321)
+    trn_loader = DataLoader(trn, args.batch * world, args.nodes)
+    val_loader = DataLoader(val, args.batch, args.nodes) if val else None
+    trainer = GraphVAETrainer(args.nodes, args.latent, args.hid, args.nodes, device=dev_, lr=args.lr, seed=args.seed,
+                              max_batch=args.batch, max_edges=args.batch * args.nodes * 6)
+    gen = torch.Generator().manual_seed(args.seed + rank)
+    return train(trn_loader, val_loader, trainer, args.epochs, rank=rank, world=world, generator=gen,
+                 use_graph=args.hip_graph, save_every=args.save_every)
+
+
+if __name__ == "__main__":
+    main()

@@ -169,7 +169,7 @@ class GraphVAETrainer:
         self._B = B
 
     # ------------------------------------------------------------------ the step
-    def _launch(self, B: int, update: bool, stream: int):
+    def _launch(self, B: int, update: bool, stream: int, backward: bool = True):
         L, n, d, hid, m, f = self.L, self.n, self.d, self.hid, self.m, self.f
         p, g = self.p, self.g
         ws, wsn = ptr(self.ws), self.ws.numel()
@@ -186,6 +186,8 @@ class GraphVAETrainer:
                                 ptr(self.y1), ptr(self.out), stream), "gtg_decoder_fwd")
         check(L.gtg_bce_loss_fwd(ptr(self.out), ptr(self.target), B, n, self.scalars.data_ptr(), ws, wsn, stream),
               "gtg_bce_loss_fwd")
+        if not backward:
+            return
         # ---- backward ---------------------------------------------------------
         check(L.gtg_decoder_bwd(ptr(self.z), ptr(p["decoder.decode_1.weight"]), ptr(p["decoder.decode_2.weight"]),
                                 ptr(self.y1), ptr(self.out), None, ptr(self.target), n, 1.0, None, B, d, hid, m,
@@ -248,6 +250,25 @@ class GraphVAETrainer:
         self.load_batch(batch, eps)
         res = self.run_loaded(update, use_graph)
         self.last_out = self.out[: self._B]
+        return res
+
+    @torch.no_grad()
+    def evaluate(self, batch: GraphBatch, eps: torch.Tensor, report: bool = True):
+        """Forward only (the dev() pass of train.py:228-282): reconstruction loss,
+        KL and, with ``report``, the batch means of edge recall / precision of
+        the maximum-spanning-tree read-out against the gold edges."""
+        from . import functional as Fn
+        from .maxspantree import mst_graph_batched
+
+        self.load_batch(batch, eps)
+        self._launch(self._B, False, torch.cuda.current_stream(self.dev).cuda_stream, backward=False)
+        self.last_out = self.out[: self._B]
+        res = {"recon": self.scalars[0].clone(), "kl": self.scalars[1].clone()}
+        if report:
+            edges, count = mst_graph_batched(self.last_out, self.n)
+            rec, prec = Fn.edge_precision_recall(edges, count, batch.gold_bits, self.n)
+            res["edge_recall"], res["edge_precision"] = rec.mean(), prec.mean()
+            res["edges"], res["count"] = edges, count
         return res
 
     def edges_ok(self) -> bool:

@@ -41,6 +41,15 @@ int gtg_version(void);
 const char* gtg_last_error(void);
 int gtg_max_nodes(void);
 
+/* Optional timing of the GEMM and MST kernel launches with HIP event pairs on
+ * the caller's stream (used by bench.py for the roofline figures; the only
+ * entry points that create events or synchronise; not valid under graph
+ * capture).  gtg_profile_report writes one line per distinct launch,
+ * "<kernel> <dim0> <dim1> <dim2> <count> <total_ms>", clears the records and
+ * returns the length of the full report. */
+int gtg_profile_enable(int on);
+int64_t gtg_profile_report(char* buf, size_t cap);
+
 /* ---- maximum-spanning-tree read-out ------------------------------------
  * Replaces mst_graph / helper_mst / maximumSpanningTree / findMaxVertex /
  * printMaximumSpanningTree (src/maxspantree.py:118-163, 61-115, 7-31, 35-58),
