@@ -37,7 +37,7 @@ struct KArgs {
     int lda, ldb, ldc, ldaux;
     int tiles_m, tiles_n, splits, k_per_split;
     int epi;
-    int vecA, vecB;
+    int vecA, vecB, vecC, vecAux;
     int to_slabs;  // write raw partials to C viewed as [batch*splits][M][N]
 };
 
@@ -65,9 +65,31 @@ struct Tile {
     static constexpr int NV = ROWS * BK / 4 / NTHREADS;
     static constexpr int V4 = ROWS / 4;
 
+    // Interior tiles with 16-byte-aligned rows take the branch-free path: NV
+    // independent 16-byte loads issued back to back.
+    __device__ static __forceinline__ void fetch_fast(f32x4 (&reg)[NV], const float* __restrict__ base, int ld, int row0,
+                                                      int k0, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NTHREADS;
+            if (KC) {
+                const int row = idx >> 3, c4 = idx & 7;
+                reg[i] = *reinterpret_cast<const f32x4*>(base + (long long)(row0 + row) * ld + (k0 + c4 * 4));
+            } else {
+                const int kk = idx / V4, c4 = idx % V4;
+                reg[i] = *reinterpret_cast<const f32x4*>(base + (long long)(k0 + kk) * ld + (row0 + c4 * 4));
+            }
+        }
+    }
+
     __device__ static __forceinline__ void fetch(f32x4 (&reg)[NV], const float* __restrict__ base, int ld, int row0,
                                                  int rows_total, int k0, int k_end, bool vec, int tid)
     {
+        if (vec && row0 + ROWS <= rows_total && k0 + BK <= k_end) {  // block-uniform
+            fetch_fast(reg, base, ld, row0, k0, tid);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * NTHREADS;
@@ -143,7 +165,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::SIZE + TB::SIZE)];
+    // operand double buffers; reused by the epilogue to stage the accumulators
+    constexpr int LDC = WTN + 4;
+    constexpr int SMEM_MAIN = 2 * (TA::SIZE + TB::SIZE), SMEM_EPI = 4 * WTM * LDC;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
     float* const sA0 = smem;
     float* const sB0 = smem + TA::SIZE;
     float* const sA1 = smem + TA::SIZE + TB::SIZE;
@@ -176,6 +201,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // Software pipeline: the registers ra/rb hold tile kt+1 (fetched one full
+    // iteration earlier); they are written to the idle LDS buffer after the
+    // first k group's MFMAs have been issued, and re-used at once for the
+    // fetch of tile kt+2, so the staging traffic sits in the shadow of the
+    // MFMA stream and a global load has a whole iteration to land.
     f32x4 ra[TA::NV], rb[TB::NV];
     const int nk = (k_end - k_begin + BK - 1) / BK;
     if (nk > 0) {
@@ -183,18 +213,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
         TB::fetch(rb, B, a.ldb, n0, a.N, k_begin, k_end, a.vecB, tid);
         TA::stage(sA0, ra, tid);
         TB::stage(sB0, rb, tid);
+        if (nk > 1) {
+            TA::fetch(ra, A, a.lda, m0, a.M, k_begin + BK, k_end, a.vecA, tid);
+            TB::fetch(rb, B, a.ldb, n0, a.N, k_begin + BK, k_end, a.vecB, tid);
+        }
     }
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const float* cA = (kt & 1) ? sA1 : sA0;
         const float* cB = (kt & 1) ? sB1 : sB0;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            const int k0 = k_begin + (kt + 1) * BK;
-            TA::fetch(ra, A, a.lda, m0, a.M, k0, k_end, a.vecA, tid);
-            TB::fetch(rb, B, a.ldb, n0, a.N, k0, k_end, a.vecB, tid);
-        }
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             f32x4 fa[TM], fb[TN];
@@ -209,10 +237,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            TA::stage((kt & 1) ? sA0 : sA1, ra, tid);
-            TB::stage((kt & 1) ? sB0 : sB1, rb, tid);
+            if (g == 0) {
+                if (kt + 1 < nk) {
+                    TA::stage((kt & 1) ? sA0 : sA1, ra, tid);
+                    TB::stage((kt & 1) ? sB0 : sB1, rb, tid);
+                }
+                if (kt + 2 < nk) {
+                    const int k0 = k_begin + (kt + 2) * BK;
+                    TA::fetch(ra, A, a.lda, m0, a.M, k0, k_end, a.vecA, tid);
+                    TB::fetch(rb, B, a.ldb, n0, a.N, k0, k_end, a.vecB, tid);
+                }
+            }
         }
         __syncthreads();
     }
@@ -263,33 +298,84 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
         ldc = a.ldc;
     }
     const float* __restrict__ aux = a.aux ? a.aux + batch * a.strideAux : nullptr;
+    const int epi = a.to_slabs ? (int)EPI_STORE : a.epi;
+    const float* __restrict__ bias = a.to_slabs ? nullptr : a.bias;
+
+    // Stage the wave's WTM x WTN accumulator tile through LDS (the operand
+    // buffers are free after the last barrier of the main loop) so that global
+    // stores -- and the aux / C loads of the mask and accumulate epilogues --
+    // are whole 16-byte row segments, 4 or 8 full rows per wave instruction,
+    // instead of one dword per lane per accumulator register.
+    float* sC = smem + wave * (WTM * LDC);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn + 32 * j + r;
-        if (col >= a.N) continue;
-        const float bias = (a.bias != nullptr && !a.to_slabs) ? a.bias[col] : 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= a.M) continue;
-                float v = acc[i][j][e];
-                float* dst = C + (long long)row * ldc + col;
-                if (a.to_slabs) {
-                    *dst = v;
-                    continue;
+            for (int e = 0; e < 16; ++e)
+                sC[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + 32 * j + r] = acc[i][j][e];
+    __syncthreads();
+
+    constexpr int LPR = WTN / 4;   // lanes per row
+    constexpr int RPI = 64 / LPR;  // rows per wave instruction
+    constexpr int NIT = WTM / RPI;
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int gcol = n0 + wn + c4 * 4;
+    const bool vec_ok = a.vecC && gcol + 3 < a.N;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (gcol + q < a.N) bv[q] = bias[gcol + q];
+    }
+    f32x4 xv[NIT];
+    if (epi == EPI_MASK || epi == EPI_ACCUM) {
+        const float* __restrict__ src = (epi == EPI_MASK) ? aux : C;
+        const int lds = (epi == EPI_MASK) ? a.ldaux : ldc;
+        const bool vsrc = (epi == EPI_MASK) ? (a.vecAux && gcol + 3 < a.N) : vec_ok;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int grow = m0 + wm + it * RPI + rsub;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (grow < a.M && gcol < a.N) {
+                const float* p = src + (long long)grow * lds + gcol;
+                if (vsrc) {
+                    t = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (gcol + q < a.N) t[q] = p[q];
                 }
-                v += bias;
-                switch (a.epi) {
-                    case EPI_RELU: v = fmaxf(v, 0.f); break;
-                    case EPI_SIGMOID: v = 1.f / (1.f + expf(-v)); break;
-                    case EPI_MASK: v = (aux[(long long)row * a.ldaux + col] > 0.f) ? v : 0.f; break;
-                    case EPI_ACCUM: v += *dst; break;
-                    default: break;
-                }
-                *dst = v;
             }
+            xv[it] = t;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int lrow = it * RPI + rsub;
+        const int grow = m0 + wm + lrow;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&sC[lrow * LDC + c4 * 4]);
+        if (grow >= a.M || gcol >= a.N) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float y = v[q] + bv[q];
+            switch (epi) {
+                case EPI_RELU: y = fmaxf(y, 0.f); break;
+                case EPI_SIGMOID: y = 1.f / (1.f + expf(-y)); break;
+                case EPI_MASK: y = (xv[it][q] > 0.f) ? y : 0.f; break;
+                case EPI_ACCUM: y += xv[it][q]; break;
+                default: break;
+            }
+            v[q] = y;
+        }
+        float* dst = C + (long long)grow * ldc + gcol;
+        if (vec_ok) {
+            *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (gcol + q < a.N) dst[q] = v[q];
+        }
     }
 }
 
@@ -421,6 +507,11 @@ int gemm(const GemmDesc& d, hipStream_t s)
     k.k_per_split = kps;
     k.to_slabs = splits > 1 ? 1 : 0;
     if (k.to_slabs) k.C = d.slabs;
+    if (k.to_slabs)
+        k.vecC = ((reinterpret_cast<uintptr_t>(d.slabs) & 15) == 0) && (d.N % 4 == 0) && (((long long)d.M * d.N) % 4 == 0);
+    else
+        k.vecC = ((reinterpret_cast<uintptr_t>(d.C) & 15) == 0) && (d.ldc % 4 == 0) && (d.strideC % 4 == 0);
+    k.vecAux = d.aux && ((reinterpret_cast<uintptr_t>(d.aux) & 15) == 0) && (d.ldaux % 4 == 0) && (d.strideAux % 4 == 0);
 
     const long long grid = (long long)k.tiles_m * k.tiles_n * splits * d.batch;
     if (grid > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "gemm: grid too large");

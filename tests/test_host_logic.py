@@ -1,0 +1,162 @@
+"""Host-side logic that needs no GPU: the batch builder (input contract of the
+hot path), module state_dict names, word_drop, shard arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+from gtg_vae_amd.data import (DataLoader, collate, gold_bitmask, prep_data_list, prep_graph, synth_graph_batch,
+                              synth_graph_list)
+from gtg_vae_amd.parallel import shard_range
+
+
+def _reference_rules(graph, maxnode):
+    """Literal restatement of /root/reference/src/train.py:177-201 (list scans and all)."""
+    n = len(graph["nodes"])
+    if n > maxnode or "edges" not in graph:
+        return None
+    edges, gold = [], []
+    adj = np.zeros((n, n))
+    for e in graph["edges"]:
+        s, t = e["source"], e["target"]
+        edges.append((s, t))
+        edges.append((t, s))
+        if (s, s) not in edges:
+            edges.append((s, s))
+        if (t, t) not in edges:
+            edges.append((t, t))
+        if s != t:
+            gold.append((s, t))
+            adj[s, t] = 1
+            adj[t, s] = 1
+    adj = adj + np.identity(n)
+    pad = np.zeros((maxnode, maxnode))
+    pad[:n, :n] = adj
+    return edges, set(gold), pad
+
+
+def test_prep_graph_follows_the_reference_rules():
+    rng = np.random.default_rng(0)
+    for trial in range(50):
+        n = int(rng.integers(1, 9))
+        ne = int(rng.integers(0, 12))
+        g = {"nodes": [{}] * n, "input": "s%d" % trial,
+             "edges": [{"source": int(rng.integers(0, n)), "target": int(rng.integers(0, n))} for _ in range(ne)]}
+        want = _reference_rules(g, 8)
+        got = prep_graph(g, 8)
+        assert got.edge_index.t().tolist() == [list(e) for e in want[0]]
+        assert got.gold_edges == want[1]
+        assert np.array_equal(got.adj_padded, want[2])
+        assert got.adj_padded.dtype == np.float64 and got.snts == "s%d" % trial
+        assert torch.equal(got.x, torch.eye(8))
+
+
+def test_oversized_and_edgeless_graphs_are_skipped():
+    big = {"nodes": [{}] * 11, "edges": []}
+    noedges = {"nodes": [{}] * 3}
+    ok = {"nodes": [{}] * 3, "edges": [{"source": 0, "target": 1}]}
+    assert len(prep_data_list([big, noedges, ok], 10)) == 1
+
+
+def test_collate_offsets_batch_vector_and_gold_bits():
+    ds = synth_graph_list(5, 10, seed=1)
+    b = collate(ds, 10)
+    assert b.num_graphs == 5 and b.batch.tolist() == sum(([g] * 10 for g in range(5)), [])
+    off = 0
+    for g, d in enumerate(ds):
+        e = d.edge_index.shape[1]
+        assert torch.equal(b.edge_index[:, off:off + e], d.edge_index + g * 10)
+        off += e
+    assert b.adj_padded.shape == (5, 10, 10) and b.adj_padded.dtype == torch.float32
+    bits = gold_bitmask(b.gold_edges, 10).numpy().view(np.uint64)
+    for g, es in enumerate(b.gold_edges):
+        for a in range(10):
+            for c in range(10):
+                assert bool((bits[g, a] >> np.uint64(c)) & np.uint64(1)) == ((a, c) in es)
+    assert torch.equal(b.dense_x(), torch.eye(10).repeat(5, 1))
+
+
+def test_dataloader_batches_and_ragged_tail():
+    ds = synth_graph_list(70, 10, seed=2)
+    sizes = [b.num_graphs for b in DataLoader(ds, 64)]
+    assert sizes == [64, 6]
+
+
+def test_synthetic_graph_shape():
+    b = synth_graph_batch(64, 32, seed=3)
+    n = b.num_nodes
+    assert int(n.min()) >= 8 and int(n.max()) <= 32
+    # symmetric targets with unit diagonal on real nodes and zero padding
+    assert torch.equal(b.adj_padded, b.adj_padded.transpose(1, 2))
+    for g in range(64):
+        k = int(n[g])
+        assert torch.all(torch.diagonal(b.adj_padded[g])[:k] == 1) and b.adj_padded[g, k:].abs().sum() == 0
+
+
+def test_shard_range_partitions_every_batch():
+    for total in (0, 1, 7, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_slice_batch_renumbers_graphs():
+    from gtg_vae_amd.train import slice_batch
+
+    b = synth_graph_batch(8, 10, seed=4)
+    s = slice_batch(b, 3, 7)
+    assert s.num_graphs == 4 and torch.equal(s.adj_padded, b.adj_padded[3:7])
+    ref = collate(synth_graph_list(8, 10, seed=4)[3:7], 10)
+    assert torch.equal(s.edge_index, ref.edge_index) and s.gold_edges == ref.gold_edges
+
+
+def test_state_dict_keys_match_the_reference_names():
+    from gtg_vae_amd import GTVAE, GraphVAE
+
+    g = GraphVAE(10, 32, 512, 10, 1)
+    assert sorted(g.state_dict()) == sorted([
+        "encoder.conv1.bias", "encoder.conv1.lin.weight", "encoder.conv2.bias", "encoder.conv2.lin.weight",
+        "decoder.decode_1.weight", "decoder.decode_1.bias", "decoder.decode_2.weight", "decoder.decode_2.bias"])
+    assert g.state_dict()["encoder.conv1.lin.weight"].shape == (64, 10)
+    assert g.state_dict()["decoder.decode_2.weight"].shape == (55, 512)
+    m = GTVAE(10, 32, 512, 10, 100, 0)
+    keys = set(m.state_dict())
+    for k in ("zg_mu.weight", "zg_var.bias", "graph_vae.encoder.conv2.lin.weight", "text_vae.embed.weight",
+              "text_vae.proj.bias", "text_vae.E.weight_ih_l0_reverse", "text_vae.G.weight_hh_l0",
+              "text_vae.hgen.weight", "text_vae.z2emb.bias"):
+        assert k in keys, k
+    # torch_geometric 1.x checkpoints name the GCN weight `weight` with shape (in, out)
+    sd = g.state_dict()
+    old = {k.replace("lin.weight", "weight"): (v.t().contiguous() if "lin.weight" in k else v) for k, v in sd.items()}
+    g2 = GraphVAE(10, 32, 512, 10, 1)
+    g2.load_state_dict(old)
+    assert torch.equal(g2.encoder.conv1.lin.weight, g.encoder.conv1.lin.weight)
+
+
+def test_decoder_init_matches_the_reference_initialiser():
+    from gtg_vae_amd import GraphVAE
+
+    torch.manual_seed(0)
+    g = GraphVAE(10, 32, 512, 10, 1)
+    w = g.decoder.decode_2.weight
+    bound = (2.0 ** 0.5) * (6.0 / (512 + 55)) ** 0.5  # xavier_uniform with relu gain (graph_vae.py:122-124)
+    assert w.abs().max().item() <= bound and w.abs().max().item() > 0.9 * bound
+    assert g.encoder.conv1.bias.abs().sum().item() == 0.0
+
+
+def test_word_drop_keeps_start_and_order():
+    from gtg_vae_amd.noise import word_drop
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.arange(1, 1 + 12 * 5).reshape(12, 5)
+    y = word_drop(0, x, 0.3, generator=g)
+    assert y.shape == x.shape and torch.equal(y[0], x[0])
+    for c in range(5):
+        col = y[:, c].tolist()
+        kept = [v for v in col if v != 0]
+        assert col == kept + [0] * (12 - len(kept))          # pads only at the end
+        assert kept == sorted(kept) and set(kept) <= set(x[:, c].tolist())  # order preserved
+    assert not torch.equal(y, x)
+    assert torch.equal(word_drop(0, x, 0.0), x)

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Launch one GEMM shape a few times (for rocprofv3 --pmc passes).
+usage: gemm_one.py {nt|nn|nnmask|tn} [reps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from gtg_vae_amd import functional as Fn
+
+which = sys.argv[1] if len(sys.argv) > 1 else "nt"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+BN, H, D = 32768, 1024, 512
+torch.manual_seed(0)
+if which == "nt":
+    A, B, akc, bkc, epi, aux = torch.randn(BN, H, device="cuda"), torch.randn(D, H, device="cuda"), True, True, 0, None
+elif which == "nn":
+    A, B, akc, bkc, epi, aux = torch.randn(BN, D, device="cuda"), torch.randn(D, H, device="cuda"), True, False, 0, None
+elif which == "nnmask":
+    A, B, akc, bkc, epi = torch.randn(BN, D, device="cuda"), torch.randn(D, H, device="cuda"), True, False, 3
+    aux = torch.randn(BN, H, device="cuda")
+else:
+    A, B, akc, bkc, epi, aux = torch.randn(BN, D, device="cuda"), torch.randn(BN, H, device="cuda"), False, False, 0, None
+for _ in range(reps):
+    out = Fn.gemm(A, B, akc, bkc, epilogue=epi, aux=aux)
+torch.cuda.synchronize()
+print("done", which, out.shape)
