@@ -32,141 +32,227 @@ constexpr float NEG_SENTINEL = -9223372036854775808.0f;  // float(-(2^63 - 1))
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// dpp_ctrl encodings (gfx9): quad_perm, row_half_mirror, row_mirror, row_bcast15/31
-constexpr int DPP_QUAD_XOR1 = 0xB1;
-constexpr int DPP_QUAD_XOR2 = 0x4E;
-constexpr int DPP_ROW_HALF_MIRROR = 0x141;
-constexpr int DPP_ROW_MIRROR = 0x140;
-constexpr int DPP_ROW_BCAST15 = 0x142;
-constexpr int DPP_ROW_BCAST31 = 0x143;
+typedef float f32x32 __attribute__((ext_vector_type(32)));
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_max(float v)
-{
-    const int t = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-    return fmaxf(v, __int_as_float(t));
-}
-
-// Maximum over the 64 lanes, returned as a wave-uniform value.
+// Maximum over the 64 lanes, NaN lanes ignored (v_max_f32 returns the other
+// operand for a quiet NaN), returned wave-uniform.  Six DPP steps: xor-1 and
+// xor-2 inside quads, half-row and row mirrors (every lane then holds the max
+// of its row of 16), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2
+// and 3; lane 63 ends up holding the wave maximum.  Written as one asm block
+// so that each step is a single v_max_f32_dpp; the s_nop 1 in front of every
+// step is the 2 wait states a DPP read needs after a VALU write of its source.
 __device__ __forceinline__ float wave_max_uniform(float v)
 {
-    v = dpp_max<DPP_QUAD_XOR1, 0xF>(v);
-    v = dpp_max<DPP_QUAD_XOR2, 0xF>(v);
-    v = dpp_max<DPP_ROW_HALF_MIRROR, 0xF>(v);
-    v = dpp_max<DPP_ROW_MIRROR, 0xF>(v);       // every lane: max of its row of 16
-    v = dpp_max<DPP_ROW_BCAST15, 0xA>(v);      // rows 1,3 += rows 0,2
-    v = dpp_max<DPP_ROW_BCAST31, 0xC>(v);      // rows 2,3 += rows 0,1 -> lane 63 holds all
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    float mx;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %1, %0, 63\n\t"
+        "s_nop 3"   // the compiler cannot see that a VALU instruction wrote this SGPR: pad its hazards here
+        : "+v"(v), "=s"(mx));
+    return mx;
 }
 
-template <bool TRIU>
-__global__ __launch_bounds__(WAVES * 64) void mst_kernel(const float* __restrict__ in, int64_t G, int n,
+// Asynchronous global -> LDS copy of one upper-triangular row (m_tri floats)
+// into the wave's LDS region: LDS-DMA loads, no registers involved; the data
+// is complete after the wave's next s_waitcnt vmcnt(0).  16-byte pieces when
+// the row is 16-byte aligned, dword pieces otherwise.
+template <bool N64>
+__device__ __forceinline__ void stage_row_async(const float* __restrict__ row, float* T, int m_tri, bool vec16, int lane)
+{
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    if (N64 && vec16) {
+        // n = 64: 2080 floats = 8 full 1-KiB pieces + one 128-byte piece, no loop, no per-piece guard
+        const float* src = row + 4 * lane;
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + 256 * it), (lptr_t)(T + 256 * it), 16, 0, 0);
+        if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(src + 2048), (lptr_t)(T + 2048), 16, 0, 0);
+    } else if (vec16) {
+        const int m4 = m_tri >> 2;
+#pragma unroll 1
+        for (int base = 0; base < m4; base += 64) {
+            const int k = base + lane;
+            if (k < m4)
+                __builtin_amdgcn_global_load_lds((gptr_t)(row + 4 * k), (lptr_t)(T + 4 * base), 16, 0, 0);
+        }
+    } else {
+#pragma unroll 1
+        for (int base = 0; base < m_tri; base += 64) {
+            const int k = base + lane;
+            if (k < m_tri) __builtin_amdgcn_global_load_lds((gptr_t)(row + k), (lptr_t)(T + base), 4, 0, 0);
+        }
+    }
+}
+
+// Persistent: every wave walks graphs g = wave id, wave id + #waves, ...  For
+// upper-triangular input the next graph's row is already in flight (LDS-DMA)
+// while the current graph's spanning tree is computed from registers.
+template <bool TRIU, bool N64>
+__global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const float* __restrict__ in, int64_t G, int n,
                                                          int32_t* __restrict__ edges, int32_t* __restrict__ count)
 {
     constexpr int PER_WAVE = TRIU ? (MAXN * (MAXN + 1) / 2) : (MAXN * (MAXN + 1));
     __shared__ __attribute__((aligned(16))) float lds[WAVES * PER_WAVE];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t g = (int64_t)blockIdx.x * WAVES + wave;
-    const bool valid = g < G;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+    if (N64) n = 64;  // lets the triangular offsets below fold to constants
     float* T = lds + wave * PER_WAVE;
     const int m_tri = n * (n + 1) / 2;
+    const bool vec16 = (m_tri & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
 
-    // ---- stage the graph's weights into LDS (coalesced global reads) --------
-    if (valid) {
+    const int j = lane;
+    const int jc = (j < n) ? j : 0;  // lanes past n read vertex 0's row; their values are never used
+    const int cj = jc * n - (jc * (jc - 1)) / 2 - jc;
+
+    int64_t g = (int64_t)blockIdx.x * WAVES + wave;
+    if (TRIU && g < G) stage_row_async<N64>(in + g * m_tri, T, m_tri, vec16, lane);
+
+    for (; g < G; g += nwaves) {
         if (TRIU) {
-            const float* row = in + g * m_tri;
-            if ((m_tri & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) & 15) == 0)) {
-                const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
-                for (int k = lane; k < (m_tri >> 2); k += 64) reinterpret_cast<f32x4*>(T)[k] = row4[k];
-            } else {
-                for (int k = lane; k < m_tri; k += 64) T[k] = row[k];
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this graph's row has landed
         } else {
-            // T[c*(MAXN+1) + r] = mat[r][c]
+            // full matrices: staged transposed, T[c*(MAXN+1) + r] = mat[r][c]
             const float* mat = in + g * n * n;
             for (int idx = lane; idx < n * n; idx += 64) {
                 const int r = idx / n, c = idx - r * n;
                 T[c * (MAXN + 1) + r] = mat[idx];
             }
         }
-    }
-    __syncthreads();
-    if (!valid) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-    const int j = lane;
-    // ---- present set: diagonal > 0.5 ---------------------------------------
-    float diag = 0.f;
-    if (j < n) diag = TRIU ? T[j * n - (j * (j - 1)) / 2] : T[j * (MAXN + 1) + j];
-    const unsigned long long present = __ballot(j < n && diag > 0.5f);
-    const int V = __popcll(present);
-    int32_t* eout = edges + g * 2 * (n - 1);
+        // ---- lane j takes row j of the matrix into registers: T[j][m] ---------
+        // (upper-triangular input: U[min(j,m)][max(j,m)], element (i,k), i <= k,
+        //  at i*n - i(i-1)/2 + (k - i)).  The Prim loop needs no memory access.
+        f32x32 lo, hi;
+        // Element (j,c) of the symmetric matrix is U[min(j,c)][max(j,c)], at
+        // triangular offset min(j + cc, cj + c) with cc = c*n - c(c-1)/2 - c and
+        // cj likewise for j: the wrong candidate always lies past the right one
+        // because every row of the triangle is longer than the distance walked
+        // back into it.  So one add, one min and one read per element, no
+        // compare masks.  The two lane constants are laundered through an empty
+        // asm so that the 64 addresses are not hoisted out of the graph loop
+        // (they would cost 64 registers).
+        typedef __attribute__((address_space(3))) const float* lds_cptr;
+        int pj4 = (int)(uintptr_t)(__attribute__((address_space(3))) float*)T + 4 * jc;
+        int pcj4 = (int)(uintptr_t)(__attribute__((address_space(3))) float*)T + 4 * cj;
+        asm volatile("" : "+v"(pj4), "+v"(pcj4));
+#pragma unroll
+        for (int c = 0; c < 64; ++c) {
+            float v;
+            if (TRIU) {
+                const int cc = c * n - (c * (c - 1)) / 2 - c;
+                const int addr = min(pj4 + 4 * (cc - c), pcj4) + 4 * c;
+                v = *(lds_cptr)(uintptr_t)addr;
+            } else {
+                v = T[c * (MAXN + 1) + jc];
+            }
+            if (c < 32)
+                lo[c] = v;
+            else
+                hi[c - 32] = v;
+            // bound the reads in flight: their destinations count against the 128-register budget
+            if ((c & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+        }
+        const float diag = TRIU ? T[jc * n - (jc * (jc - 1)) / 2] : T[jc * (MAXN + 1) + jc];
+        // every LDS read above has returned (waited for just below): the
+        // region may be overwritten by the next graph's row now
+        if (TRIU) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t gn = g + nwaves;
+            if (gn < G) stage_row_async<N64>(in + gn * m_tri, T, m_tri, vec16, lane);
+        }
 
-    if (V == 0) {
-        if (j < n - 1) {
+        // ---- present set: diagonal > 0.5 -----------------------------------
+        const unsigned long long present = __ballot(j < n && diag > 0.5f);
+        const int V = __popcll(present);
+        int32_t* eout = edges + g * 2 * (n - 1);
+        if (V == 0) {
+            if (j < n - 1) {
+                eout[2 * j] = -1;
+                eout[2 * j + 1] = -1;
+            }
+            if (j == 0) count[g] = 0;
+            continue;
+        }
+        const int root = __ffsll((long long)present) - 1;
+        const int last = 63 - __clzll((long long)present);
+        const bool pj = (present >> j) & 1ull;
+
+        // w: best weight reaching vertex j so far; -2^63 = not reached yet;
+        // quiet NaN = visited or absent (never selected: max skips NaN; never
+        // updated: t > NaN is false).
+        float w = pj ? NEG_SENTINEL : __builtin_nanf("");
+        int parent = root;
+        // One round: visit m, then let column m improve every unvisited vertex.
+        // Row element m is fetched from both register halves with one indexed
+        // move each and selected by a scalar condition (no branch).
+#define GTG_MST_VISIT(m_)                                                    \
+        {                                                                        \
+            const int mm = (m_);                                                 \
+            float tl = lo[mm & 31], th = hi[mm & 31];                            \
+            asm volatile("" : "+v"(tl), "+v"(th));                               \
+            const float t = (mm < 32) ? tl : th;                                 \
+            w = (j == mm) ? __builtin_nanf("") : w;                              \
+            const bool upd = (t != 0.f) && (t > w);                              \
+            w = upd ? t : w;                                                     \
+            parent = upd ? mm : parent;                                          \
+        }
+        if (V > 1) GTG_MST_VISIT(root)  // round 0: weights[root] = +maxsize wins
+        for (int round = 1; round < V - 1; ++round) {
+            const float mx = wave_max_uniform(w);
+            const unsigned long long eq = __ballot(w == mx);
+            const int first = __ffsll((long long)eq) - 1;
+            // nothing reached yet -> Python's index -1 = the last present vertex
+            const int m = __builtin_amdgcn_readfirstlane(
+                (__float_as_int(mx) == __float_as_int(NEG_SENTINEL)) ? last : first);
+            GTG_MST_VISIT(m)
+        }
+#undef GTG_MST_VISIT
+
+        // ---- ordered output: slot (local index - 1) <- (parent, vertex) -----
+        if (pj && j != root) {
+            const int li = __popcll(present & ((1ull << j) - 1ull));
+            eout[2 * (li - 1)] = parent;
+            eout[2 * (li - 1) + 1] = j;
+        }
+        if (j >= V - 1 && j < n - 1) {
             eout[2 * j] = -1;
             eout[2 * j + 1] = -1;
         }
-        if (j == 0) count[g] = 0;
-        return;
+        if (j == 0) count[g] = V - 1;
     }
-
-    const int root = __ffsll((long long)present) - 1;
-    const int last = 63 - __clzll((long long)present);
-    const bool pj = (present >> j) & 1ull;
-    const int cj = j * n - (j * (j - 1)) / 2 - j;  // triu: U[j][m] (m > j) sits at cj + m
-
-    float w = NEG_SENTINEL;
-    int parent = root;
-    unsigned long long visited = 0ull;
-
-    for (int round = 0; round < V - 1; ++round) {
-        int m;
-        if (round == 0) {
-            m = root;
-        } else {
-            const bool elig = pj && !((visited >> j) & 1ull) && (w > NEG_SENTINEL);
-            const unsigned long long em = __ballot(elig);
-            if (em == 0ull) {
-                m = last;
-            } else {
-                const float mx = wave_max_uniform(elig ? w : -__builtin_inff());
-                const unsigned long long eq = __ballot(elig && w == mx);
-                m = __ffsll((long long)eq) - 1;
-            }
-        }
-        m = __builtin_amdgcn_readfirstlane(m);
-        visited |= (1ull << m);
-        float t;
-        if (TRIU) {
-            const int cm = m * n - (m * (m - 1)) / 2 - m;
-            const int idx = (j > m) ? (cm + j) : (cj + m);
-            t = T[(j < n) ? idx : 0];
-        } else {
-            t = T[m * (MAXN + 1) + j];
-        }
-        const bool upd = pj && !((visited >> j) & 1ull) && (t != 0.f) && (t > w);
-        if (upd) {
-            w = t;
-            parent = m;
-        }
-    }
-
-    // ---- ordered output: slot (local index - 1) <- (parent, vertex) ---------
-    if (pj && j != root) {
-        const int li = __popcll(present & ((1ull << j) - 1ull));
-        eout[2 * (li - 1)] = parent;
-        eout[2 * (li - 1) + 1] = j;
-    }
-    if (j >= V - 1 && j < n - 1) {
-        eout[2 * j] = -1;
-        eout[2 * j + 1] = -1;
-    }
-    if (j == 0) count[g] = V - 1;
 }
 
 }  // namespace
+
+static int num_cus()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    return cus;
+}
 
 static int mst_launch(bool triu, const float* in, int64_t G, int n, int32_t* edges, int32_t* count, hipStream_t s)
 {
@@ -174,13 +260,18 @@ static int mst_launch(bool triu, const float* in, int64_t G, int n, int32_t* edg
     if (n > MAXN) return set_error(GTG_ERR_UNSUPPORTED, "mst: n=%d exceeds the one-wavefront-per-graph limit of %d", n, MAXN);
     if (G == 0 || n == 0) return GTG_OK;
     if (!in || !count || (n > 1 && !edges)) return set_error(GTG_ERR_INVALID, "mst: null pointer");
-    const int64_t blocks = (G + WAVES - 1) / WAVES;
-    if (blocks > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "mst: too many graphs for one launch");
+    // persistent grid: LDS admits 4 blocks of the triangular kernel (2 of the full-matrix
+    // one) per CU; more blocks than that only queue
+    int64_t blocks = (G + WAVES - 1) / WAVES;
+    const int64_t resident = (int64_t)num_cus() * (triu ? 4 : 2);
+    if (blocks > resident) blocks = resident;
     ProfScope prof(s, triu ? "mst_triu" : "mst_full", G, n, 0);
-    if (triu)
-        hipLaunchKernelGGL(mst_kernel<true>, dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+    if (triu && n == 64)
+        hipLaunchKernelGGL((mst_kernel<true, true>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+    else if (triu)
+        hipLaunchKernelGGL((mst_kernel<true, false>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
     else
-        hipLaunchKernelGGL(mst_kernel<false>, dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+        hipLaunchKernelGGL((mst_kernel<false, false>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
     return check_launch("mst_kernel");
 }
 
