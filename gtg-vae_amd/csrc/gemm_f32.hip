@@ -394,12 +394,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 enum TileCfg { CFG_128, CFG_64x128, CFG_64 };
 
-inline TileCfg pick_cfg(int M, int N, int batch, int epi)
+inline TileCfg pick_cfg(int M, int N, int K, int batch, int epi)
 {
     if (epi == EPI_POOL) return CFG_64x128;
     if (batch > 1 && M <= 64) return CFG_64x128;
     const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
     if (t128 >= 192) return CFG_128;
+    // short-and-wide weight-gradient shapes: the big tile still fills the chip once K is split
+    if (batch == 1 && M >= 128 && N >= 128 && t128 * (K / 1024) >= 192) return CFG_128;
     return CFG_64;
 }
 
@@ -432,7 +434,7 @@ int gemm_pick_splits(int M, int N, int K, int batch)
 {
     if (batch != 1) return 1;
     int bm, bn;
-    cfg_dims(pick_cfg(M, N, batch, EPI_STORE), bm, bn);
+    cfg_dims(pick_cfg(M, N, K, batch, EPI_STORE), bm, bn);
     const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     if (tiles >= 256 || K < 1024) return 1;
     long long want = (768 + tiles - 1) / tiles;
@@ -463,7 +465,7 @@ int gemm(const GemmDesc& d, hipStream_t s)
     }
     if (d.epi == EPI_MASK && !d.aux) return set_error(GTG_ERR_INVALID, "gemm: mask epilogue without aux");
 
-    const TileCfg cfg = pick_cfg(d.M, d.N, d.batch, d.epi);
+    const TileCfg cfg = pick_cfg(d.M, d.N, d.K, d.batch, d.epi);
     int bm, bn;
     cfg_dims(cfg, bm, bn);
 

@@ -98,42 +98,49 @@ __global__ __launch_bounds__(256) void pool_bwd_gather_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------
-// column sums (bias gradients): two ordered stages.
+// column sums (bias gradients).  A block owns 64 columns (16 lanes x 4
+// columns, 16-byte loads when the rows are aligned) and one chunk of rows,
+// walked by 16 row lanes; the row lanes are combined through LDS in a fixed
+// order.  With a single chunk the result goes straight to `out`, otherwise to
+// partial[chunk][col] and a second launch adds the chunks in order.
 // ---------------------------------------------------------------------------
-constexpr int CS_COLS = 64;   // columns per block
-constexpr int CS_RG = 4;      // row lanes per block
+constexpr int CS_COLS = 64;
+constexpr int CS_RL = 16;
 __host__ __device__ inline int cs_chunk_rows(int64_t rows)
 {
-    int64_t c = (rows + 255) / 256;
-    if (c < 64) c = 64;
-    return (int)c;
+    return rows <= 1024 ? (int)(rows > 0 ? rows : 1) : 512;
 }
 
-__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, int64_t rows, int cols, int ld,
-                                                     int chunk, float* __restrict__ partial)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t rows, int cols, int ld,
+                                                     int chunk, int vec, float* __restrict__ dst)
 {
-    __shared__ float sm[CS_RG][CS_COLS];
-    const int cl = threadIdx.x % CS_COLS, rg = threadIdx.x / CS_COLS;
-    const int col = blockIdx.x * CS_COLS + cl;
+    __shared__ f32x4 sm[CS_RL][CS_COLS / 4];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * CS_COLS + cg * 4;
     const int64_t r0 = (int64_t)blockIdx.y * chunk;
     const int64_t r1 = min(rows, r0 + chunk);
-    float s = 0.f;
-    if (col < cols)
-        for (int64_t r = r0 + rg; r < r1; r += CS_RG) s += X[r * ld + col];
-    sm[rg][cl] = s;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (col < cols) {
+        if (vec && col + 3 < cols) {
+            for (int64_t r = r0 + rl; r < r1; r += CS_RL) s += *reinterpret_cast<const f32x4*>(X + r * ld + col);
+        } else {
+            for (int64_t r = r0 + rl; r < r1; r += CS_RL)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (col + q < cols) s[q] += X[r * ld + col + q];
+        }
+    }
+    sm[rl][cg] = s;
     __syncthreads();
-    if (rg == 0 && col < cols)
-        partial[(int64_t)blockIdx.y * cols + col] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
-}
-
-__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, int nchunks, int cols,
-                                                     float* __restrict__ out)
-{
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= cols) return;
-    float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + col];
-    out[col] = s;
+    if (rl == 0 && col < cols) {
+        f32x4 t = sm[0][cg];
+#pragma unroll
+        for (int k = 1; k < CS_RL; ++k) t += sm[k][cg];
+        float* o = dst + (int64_t)blockIdx.y * cols + col;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (col + q < cols) o[q] = t[q];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -362,7 +369,7 @@ size_t colsum_workspace(int64_t rows, int cols)
 {
     const int chunk = cs_chunk_rows(rows);
     const int64_t nchunks = (rows + chunk - 1) / chunk;
-    return (size_t)nchunks * cols * sizeof(float);
+    return nchunks > 1 ? (size_t)nchunks * cols * sizeof(float) : 0;
 }
 
 int colsum(const float* X, int64_t rows, int cols, int ld, float* partial, float* out, hipStream_t s)
@@ -370,14 +377,20 @@ int colsum(const float* X, int64_t rows, int cols, int ld, float* partial, float
     if (cols == 0) return GTG_OK;
     const int chunk = cs_chunk_rows(rows);
     const int nchunks = (int)((rows + chunk - 1) / chunk);
-    if (nchunks > 0) {
-        hipLaunchKernelGGL(colsum_stage1, dim3((cols + CS_COLS - 1) / CS_COLS, nchunks), dim3(256), 0, s, X, rows, cols,
-                           ld, chunk, partial);
-        int rc = check_launch("colsum_stage1");
-        if (rc) return rc;
+    const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ld % 4 == 0);
+    const dim3 grid((cols + CS_COLS - 1) / CS_COLS, nchunks > 0 ? nchunks : 1);
+    if (nchunks <= 1) {
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, out);
+        return check_launch("colsum_kernel");
     }
-    hipLaunchKernelGGL(colsum_stage2, dim3((cols + 255) / 256), dim3(256), 0, s, partial, nchunks, cols, out);
-    return check_launch("colsum_stage2");
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, partial);
+    int rc = check_launch("colsum_kernel");
+    if (rc) return rc;
+    // second stage: the partials form an (nchunks x cols) matrix; same kernel, one chunk
+    const int vec2 = ((reinterpret_cast<uintptr_t>(partial) & 15) == 0) && (cols % 4 == 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + CS_COLS - 1) / CS_COLS, 1), dim3(256), 0, s, partial,
+                       (int64_t)nchunks, cols, cols, nchunks, vec2, out);
+    return check_launch("colsum_kernel");
 }
 
 int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z, float* kl_partial,
