@@ -185,8 +185,15 @@ def main():
             fl = 2.0 * m_ * n_ * k_
             avg_ms = tot_ms / cnt
             ach = fl / (avg_ms * 1e-3) / 1e12
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (bench.py cannot read PMCs itself)
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    traffic = json.load(f).get("%s %d %d %d" % (name, m_, n_, k_), {}).get("traffic_bytes")
+            except OSError:
+                pass
             roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": name,
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel": name,
                     "launch": {"M": m_, "N": n_, "K": k_, "flops": fl, "avg_ms": avg_ms, "launches": cnt}}
             for r in sorted(big, key=lambda r: -r[5])[:8]:
                 kern["%s M%d N%d K%d" % r[:4]] = {"avg_ms": r[5] / r[4], "tflops": 2.0 * r[1] * r[2] * r[3] / (r[5] / r[4] * 1e-3) / 1e12}
