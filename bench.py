@@ -115,10 +115,14 @@ def main():
     ap.add_argument("--no-mst", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (N=1 only; no per-kernel timing)")
     args = ap.parse_args()
+    if os.environ.get("GTG_HANG_DUMP"):  # debugging aid: dump all Python stacks if the run stalls
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["GTG_HANG_DUMP"]), exit=True)
 
     from gtg_vae_amd import _lib
     from gtg_vae_amd.data import synth_graph_batch
-    from gtg_vae_amd.parallel import init_process_group
+    from gtg_vae_amd.parallel import init_process_group, local_device_index
     from gtg_vae_amd.trainer import GraphVAETrainer
 
     rank, local_rank, world = init_process_group()
@@ -127,8 +131,8 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_device_index(local_rank))
+    torch.cuda.set_device(dev)
     N, B, d, hid = args.nodes, args.batch, args.latent, args.hid
 
     # identical initial weights on every rank, different data per rank
@@ -167,9 +171,9 @@ def main():
     recon, kl = tr.scalars[0].item(), tr.scalars[1].item()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        from gtg_vae_amd.parallel import all_reduce_small
+
+        elapsed = all_reduce_small(torch.tensor([elapsed], dtype=torch.float64, device=dev), dist.ReduceOp.MAX).item()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

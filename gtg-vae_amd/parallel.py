@@ -21,13 +21,20 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def local_device_index(local_rank: int) -> int:
+    """GPU index for this rank: LOCAL_RANK, wrapped when fewer GPUs than ranks are visible."""
+    n = torch.cuda.device_count()
+    return local_rank % n if n > 0 else 0
+
+
 def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # GTG_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL wants one GPU per rank)
+            backend = os.environ.get("GTG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world,
@@ -68,7 +75,14 @@ class GradBuckets:
     def reduce(self, i: int) -> None:
         if self.world == 1:
             return
-        self._pending.append(dist.all_reduce(self.views[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        v = self.views[i]
+        if v.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal path (several ranks on one GPU): this build's gloo does not reduce GPU tensors
+            host = v.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            v.copy_(host)
+            return
+        self._pending.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self) -> None:
         for w in self._pending:
@@ -81,9 +95,15 @@ class GradBuckets:
         self.finish()
 
 
-def all_reduce_scalars(values: torch.Tensor, group=None) -> torch.Tensor:
-    """Mean of a small tensor of per-rank scalars (reporting only)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
-        values = values / dist.get_world_size(group)
-    return values
+def all_reduce_small(values: torch.Tensor, op=None, group=None) -> torch.Tensor:
+    """All-reduce of a small reporting tensor; returns it on the CPU.  Goes
+    through host memory when the backend is gloo."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return values.cpu()
+    op = dist.ReduceOp.SUM if op is None else op
+    if dist.get_backend(group) == "gloo":
+        host = values.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        return host
+    dist.all_reduce(values, op=op, group=group)
+    return values.cpu()

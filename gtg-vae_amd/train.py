@@ -17,7 +17,7 @@ import time
 import torch
 
 from .data import DataLoader, load_mrp, prep_data_list, synth_graph_list
-from .parallel import all_reduce_scalars, init_process_group, shard_range
+from .parallel import init_process_group, local_device_index, shard_range
 from .trainer import GraphVAETrainer
 
 NKL = 500  # epochs over which the KL weight ramps to 1 (train.py:286,294)
@@ -74,9 +74,9 @@ def train(train_loader, dev_loader, trainer: GraphVAETrainer, epochs, model_name
         dt = time.perf_counter() - t0
         tot = torch.cat([sums, torch.tensor([float(n_inst)], dtype=torch.float64, device=trainer.dev)])
         if world > 1:
-            import torch.distributed as dist
+            from .parallel import all_reduce_small
 
-            dist.all_reduce(tot)
+            tot = all_reduce_small(tot)
         means = (tot[:3] / tot[3]).tolist()
         history.append({"epoch": epoch, "loss": means[0], "graph_recon": means[1], "kl": means[2],
                         "graphs_per_s": tot[3].item() / dt})
@@ -126,7 +126,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     rank, local_rank, world = init_process_group()
-    dev_ = torch.device("cuda", local_rank)
+    dev_ = torch.device("cuda", local_device_index(local_rank))
     torch.cuda.set_device(dev_)
     if args.train:
         trn = prep_data_list(load_mrp(args.train), args.nodes)
