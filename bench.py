@@ -148,6 +148,20 @@ def main():
         tr.load_batch(batches[i % nb], eps[i % nb])
         tr.run_loaded(update=True, use_graph=use_graph)
 
+    # census of the encoder's stored rows (R real + N prototype rows per batch) and per-graph extents: the launches
+    # tagged ":m"/":k"/":g" read these on the device, so their flop counts below use what was executed
+    census = []
+    for i in range(nb):
+        tr.load_batch(batches[i], eps[i])
+        tr.run_loaded(update=False)
+        torch.cuda.synchronize()
+        meta = tr.meta[: 2 * B + 2].cpu()
+        nb_real = meta[:B].double()
+        census.append({"rows": float(meta[2 * B + 1]), "sq": float((nb_real * nb_real).sum()), "sum": float(nb_real.sum())})
+    used = [(args.warmup + i) % nb for i in range(args.steps)]
+    eff_rows = sum(census[j]["rows"] for j in used) / max(1, len(used))
+    eff_sq = sum(census[j]["sq"] for j in used) / max(1, len(used))
+
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
@@ -183,10 +197,21 @@ def main():
         roof = None
         kern = {}
         big = [r for r in prof if r[0].startswith("gemm")]
+
+        def executed_flops(r):
+            name, m_, n_, k_ = r[:4]
+            if name.endswith(":m"):
+                return 2.0 * eff_rows * n_ * k_
+            if name.endswith(":k"):
+                return 2.0 * m_ * n_ * eff_rows
+            if name.endswith(":g"):     # per graph (n_b x N x n_b)
+                return 2.0 * eff_sq * n_
+            return 2.0 * m_ * n_ * k_
+
         if big:
             top = max(big, key=lambda r: r[5])
             name, m_, n_, k_, cnt, tot_ms = top
-            fl = 2.0 * m_ * n_ * k_
+            fl = executed_flops(top)
             avg_ms = tot_ms / cnt
             ach = fl / (avg_ms * 1e-3) / 1e12
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (bench.py cannot read PMCs itself)
@@ -198,9 +223,10 @@ def main():
                 pass
             roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel": name,
-                    "launch": {"M": m_, "N": n_, "K": k_, "flops": fl, "avg_ms": avg_ms, "launches": cnt}}
+                    "launch": {"M": m_, "N": n_, "K": k_, "flops": fl, "avg_ms": avg_ms, "launches": cnt,
+                               "stored_rows": eff_rows if ":" in name else None}}
             for r in sorted(big, key=lambda r: -r[5])[:8]:
-                kern["%s M%d N%d K%d" % r[:4]] = {"avg_ms": r[5] / r[4], "tflops": 2.0 * r[1] * r[2] * r[3] / (r[5] / r[4] * 1e-3) / 1e12}
+                kern["%s M%d N%d K%d" % r[:4]] = {"avg_ms": r[5] / r[4], "tflops": executed_flops(r) / (r[5] / r[4] * 1e-3) / 1e12}
         step_tflops = value * 3 * F / 1e12
         line = {
             "metric": "training graphs/sec (whole node) at N=64 nodes, batch 512; 1/2/4/8 MI355X",
@@ -212,6 +238,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "hip_graph": bool(use_graph)},
             "step_algorithmic_tflops": step_tflops,
             "step_frac_of_f32_mfma_peak": step_tflops / (PEAK_F32_MFMA_TFLOPS * world),
+            "encoder_rows": {"padded": B * N, "stored_mean": eff_rows},
             "loss": {"recon": recon, "kl": kl},
             "roofline": roof,
             "gemm_kernels": kern,

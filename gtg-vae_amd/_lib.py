@@ -33,6 +33,10 @@ _SIGS = {
     "gtg_encoder_fwd": (c_int, [_P] * 6 + [c_int64, c_int, c_int, c_int] + [_P] * 3 + [_P, c_size_t, _P]),
     "gtg_encoder_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     "gtg_encoder_bwd": (c_int, [_P] * 7 + [c_int64, c_int, c_int, c_int] + [_P] * 4 + [_P, c_size_t, _P]),
+    "gtg_encoder_compact_fwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "gtg_encoder_compact_fwd": (c_int, [_P] * 6 + [c_int64, c_int, c_int] + [_P] * 5 + [_P, c_size_t, _P]),
+    "gtg_encoder_compact_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "gtg_encoder_compact_bwd": (c_int, [_P] * 7 + [c_int64, c_int, c_int] + [_P] * 4 + [_P, c_size_t, _P]),
     "gtg_latent_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "gtg_latent_fwd": (c_int, [_P] * 6 + [c_int64, c_int] + [_P] * 4 + [_P, c_size_t, _P]),
     "gtg_latent_bwd": (c_int, [_P] * 7 + [c_float, _P, c_int64, c_int] + [_P] * 5 + [_P, c_size_t, _P]),

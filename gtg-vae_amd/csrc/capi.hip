@@ -374,6 +374,150 @@ int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const flo
 }
 
 // ---------------------------------------------------------------------------
+// encoder on compact node rows (identity node features only).
+// Rows [0, n_b) of graph b (n_b = 1 + highest node index any non-self edge
+// touches) are stored back to back; every row past n_b equals a
+// batch-independent prototype row, evaluated once per call for all n indices
+// and merged into the max-pool as a suffix maximum.  Same results as the dense
+// path, with the row-proportional GEMMs shrunk to the real rows.
+// ---------------------------------------------------------------------------
+struct EncCFwdWs {
+    float *t2c, *sval;
+    int32_t* sidx;
+};
+
+static void enc_cfwd_layout(Carver& c, int64_t B, int n, int d, EncCFwdWs* w)
+{
+    w->t2c = c.take<float>((size_t)(B * n + n) * d);
+    w->sval = c.take<float>((size_t)(n + 1) * d);
+    w->sidx = c.take<int32_t>((size_t)(n + 1) * d);
+}
+
+size_t gtg_encoder_compact_fwd_workspace_bytes(int64_t num_graphs, int n, int d)
+{
+    Carver c(nullptr, 0);
+    EncCFwdWs w;
+    enc_cfwd_layout(c, num_graphs, n, d, &w);
+    return c.off;
+}
+
+int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float* W1, const float* b1, const float* W2,
+                            const float* b2, int64_t num_graphs, int n, int d, int32_t* meta, float* adjc, float* h1c,
+                            float* pooled, int32_t* argmax, void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
+    GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
+    GTG_REQUIRE(adj && counts && W1 && b1 && W2 && b2 && meta && adjc && h1c && pooled && argmax, "null pointer");
+    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4, "batch too large");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)num_graphs, H = 2 * d, rows = B * n + n;
+    Carver c(ws, ws_bytes);
+    EncCFwdWs w;
+    enc_cfwd_layout(c, B, n, d, &w);
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_encoder_compact_fwd: workspace too small");
+    const int32_t* n_real = meta;
+    const int32_t* row_off = meta + B;
+    const int32_t* real_rows = meta + 2 * B;      // R
+    const int32_t* all_rows = meta + 2 * B + 1;   // R + n
+
+    GTG_TRY(graph_meta(counts, adj, B, n, meta, adjc, s));
+    GemmDesc g;
+    // H1c[off_b + i] = relu(A_b[:n_b,:n_b] * W1^T[:n_b] + b1)
+    g.A = adj; g.lda = n; g.a_kc = true; g.strideA = (long long)n * n;
+    g.B = W1; g.ldb = n; g.b_kc = true; g.strideB = 0;
+    g.C = h1c; g.ldc = H; g.off_c = true;
+    g.M = n; g.N = H; g.K = n; g.batch = B;
+    g.batch_dim = n_real; g.batch_off = row_off;
+    g.bias = b1; g.epi = EPI_RELU;
+    GTG_TRY(gemm(g, s));
+    // prototype rows R .. R+n-1: relu(W1^T + b1)
+    GTG_TRY(proto_h1(W1, b1, n, H, real_rows, h1c, s));
+    // T2c = H1c * W2^T over the R + n stored rows
+    g = GemmDesc();
+    g.A = h1c; g.lda = H; g.B = W2; g.ldb = H; g.C = w.t2c; g.ldc = d;
+    g.M = rows; g.N = d; g.K = H; g.m_dev = all_rows;
+    GTG_TRY(gemm(g, s));
+    // suffix maxima (+ b2) of the prototype rows over the row index
+    GTG_TRY(proto_suffix_max(w.t2c, real_rows, b2, n, d, w.sval, w.sidx, s));
+    // pooled[b] = max( max_{i<n_b}(A_b * T2c[b] + b2), suffix max of the prototype rows from n_b )
+    g = GemmDesc();
+    g.A = adj; g.lda = n; g.a_kc = true; g.strideA = (long long)n * n;
+    g.B = w.t2c; g.ldb = d; g.b_kc = false; g.off_b = true;
+    g.M = n; g.N = d; g.K = n; g.batch = B;
+    g.batch_dim = n_real; g.batch_off = row_off;
+    g.bias = b2; g.epi = EPI_POOL; g.pool_val = pooled; g.pool_idx = argmax;
+    g.proto_val = w.sval; g.proto_idx = w.sidx;
+    return gemm(g, s);
+}
+
+struct EncCBwdWs {
+    float *dT2c, *dZ1c, *pg, *cs, *slabs;
+};
+
+static void enc_cbwd_layout(Carver& c, int64_t B, int n, int d, EncCBwdWs* w)
+{
+    const size_t rows = (size_t)B * n + n;
+    const int H = 2 * d;
+    w->dT2c = c.take<float>(rows * d);
+    w->dZ1c = c.take<float>(rows * H);
+    w->pg = reinterpret_cast<float*>(c.take<char>(proto_grad_workspace(n, d)));
+    w->cs = reinterpret_cast<float*>(c.take<char>(max2(colsum_workspace(B, d), colsum_workspace((int64_t)rows, H))));
+    w->slabs = reinterpret_cast<float*>(
+        c.take<char>(max2(gemm_splitk_workspace(d, H, (int)rows, 1), gemm_splitk_workspace(H, n, (int)rows, 1))));
+}
+
+size_t gtg_encoder_compact_bwd_workspace_bytes(int64_t num_graphs, int n, int d)
+{
+    Carver c(nullptr, 0);
+    EncCBwdWs w;
+    enc_cbwd_layout(c, num_graphs, n, d, &w);
+    return c.off;
+}
+
+int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* meta, const float* W2, const float* h1c,
+                            const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int d, float* dW1,
+                            float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
+    GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
+    GTG_REQUIRE(adj && adjc && meta && W2 && h1c && argmax && dpooled && dW1 && db1 && dW2 && db2, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)num_graphs, H = 2 * d, rows = B * n + n;
+    Carver c(ws, ws_bytes);
+    EncCBwdWs w;
+    enc_cbwd_layout(c, B, n, d, &w);
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_encoder_compact_bwd: workspace too small");
+    const int32_t* all_rows = meta + 2 * B + 1;  // R + n
+
+    // dT2c: real rows from the max-pool routing, prototype rows from the graphs whose maximum they won
+    GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, s));
+    GTG_TRY(proto_grad(dpooled, argmax, meta, B, n, d, w.pg, w.dT2c, s));
+    GTG_TRY(colsum(dpooled, B, d, d, w.cs, db2, s));
+    GemmDesc g;
+    // dW2 = dT2c^T * H1c
+    g.A = w.dT2c; g.lda = d; g.a_kc = false;
+    g.B = h1c; g.ldb = H; g.b_kc = false;
+    g.C = dW2; g.ldc = H; g.M = d; g.N = H; g.K = rows; g.k_dev = all_rows;
+    g.splits = gemm_pick_splits(d, H, rows, 1); g.slabs = w.slabs;
+    GTG_TRY(gemm(g, s));
+    // dZ1c = (dT2c * W2) masked by relu
+    g = GemmDesc();
+    g.A = w.dT2c; g.lda = d; g.a_kc = true;
+    g.B = W2; g.ldb = H; g.b_kc = false;
+    g.C = w.dZ1c; g.ldc = H; g.M = rows; g.N = H; g.K = d; g.m_dev = all_rows;
+    g.epi = EPI_MASK; g.aux = h1c; g.ldaux = H;
+    GTG_TRY(gemm(g, s));
+    GTG_TRY(colsum_dev(w.dZ1c, rows, all_rows, H, H, w.cs, db1, s));
+    // dW1[c][i] = sum over stored rows dZ1c[r][c] * adjc[r][i]   (prototype rows carry unit adjacency rows)
+    g = GemmDesc();
+    g.A = w.dZ1c; g.lda = H; g.a_kc = false;
+    g.B = adjc; g.ldb = n; g.b_kc = false;
+    g.C = dW1; g.ldc = n; g.M = H; g.N = n; g.K = rows; g.k_dev = all_rows;
+    g.splits = gemm_pick_splits(H, n, rows, 1); g.slabs = w.slabs;
+    return gemm(g, s);
+}
+
+// ---------------------------------------------------------------------------
 // latent head: mu / logvar linears, reparameterisation with supplied eps, KL
 // ---------------------------------------------------------------------------
 size_t gtg_latent_workspace_bytes(int64_t num_graphs, int d)

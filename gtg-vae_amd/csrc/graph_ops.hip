@@ -112,9 +112,11 @@ __host__ __device__ inline int cs_chunk_rows(int64_t rows)
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t rows, int cols, int ld,
-                                                     int chunk, int vec, float* __restrict__ dst)
+                                                     int chunk, int vec, const int* __restrict__ rows_dev,
+                                                     float* __restrict__ dst)
 {
     __shared__ f32x4 sm[CS_RL][CS_COLS / 4];
+    if (rows_dev) rows = min(rows, (int64_t)rows_dev[0]);
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int col = blockIdx.x * CS_COLS + cg * 4;
     const int64_t r0 = (int64_t)blockIdx.y * chunk;
@@ -233,6 +235,171 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
         const float gi = gg * (p - t) / fmaxf(q, 1e-12f);
         d[k] = through_sigmoid ? gi * q : gi;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Compact node rows.  With identity node features, a node that no non-self
+// edge touches has the same encoder rows in every graph (its adjacency row and
+// column are the unit vector), so only rows [0, n_b) of graph b are stored and
+// multiplied, n_b = 1 + the highest node index an edge touches; the rows past
+// it are represented once per step by "prototype" rows.
+// meta layout (int32): [0,B) n_b ; [B, 2B] exclusive row offsets, meta[2B] = R ;
+// meta[2B+1] = R + n (the n prototype rows are stored right after the real rows, as
+// n extra nodes whose adjacency row is the unit vector, so every row-wise GEMM and
+// reduction of forward and backward covers them with no special case)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void graph_extent_kernel(const int32_t* __restrict__ counts, int n,
+                                                          int32_t* __restrict__ n_real)
+{
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int32_t* c = counts + b * n * n;
+    int touched = 0;
+    if (lane < n)
+        for (int j = 0; j < n; ++j) touched |= c[lane * n + j] | c[j * n + lane];
+    const unsigned long long m = __ballot(touched != 0);
+    if (lane == 0) n_real[b] = m ? 64 - __clzll((long long)m) : 0;
+}
+
+// exclusive scan of n_real over the batch (one block, ordered)
+__global__ __launch_bounds__(256) void graph_offsets_kernel(const int32_t* __restrict__ n_real, int B, int n,
+                                                            int32_t* __restrict__ off)
+{
+    __shared__ int part[256];
+    const int t = threadIdx.x;
+    const int per = (B + 255) / 256;
+    const int lo = t * per, hi = min(B, lo + per);
+    int s = 0;
+    for (int b = lo; b < hi; ++b) s += n_real[b];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < 256; ++k) {
+            const int v = part[k];
+            part[k] = run;
+            run += v;
+        }
+        off[B] = run;          // R: rows of real nodes
+        off[B + 1] = run + n;  // R + n: the n prototype rows follow them
+    }
+    __syncthreads();
+    int run = part[t];
+    for (int b = lo; b < hi; ++b) {
+        off[b] = run;
+        run += n_real[b];
+    }
+}
+
+// adjc[off[b] + j, :] = adj[b, j, :] for j < n_b; block B writes the n identity rows at R
+__global__ __launch_bounds__(256) void adj_compact_kernel(const float* __restrict__ adj, const int32_t* __restrict__ meta,
+                                                         int64_t B, int n, float* __restrict__ adjc)
+{
+    const int64_t b = blockIdx.x;
+    if (b == B) {
+        const int R = meta[2 * B];
+        for (int idx = threadIdx.x; idx < n * n; idx += 256)
+            adjc[(int64_t)R * n + idx] = (idx / n == idx % n) ? 1.f : 0.f;
+        return;
+    }
+    const int nb = meta[b], off = meta[B + b];
+    const float* src = adj + b * n * n;
+    float* dst = adjc + (int64_t)off * n;
+    for (int idx = threadIdx.x; idx < nb * n; idx += 256) dst[idx] = src[idx];
+}
+
+// P1[i][c] = relu(W1[c][i] + b1[c])  (first-layer row of an untouched node i)
+__global__ __launch_bounds__(256) void proto_h1_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int n,
+                                                       int H, const int32_t* __restrict__ row_base,
+                                                       float* __restrict__ h1c)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * H) return;
+    const int i = idx / H, c = idx - i * H;
+    h1c[(int64_t)row_base[0] * H + idx] = fmaxf(W1[(int64_t)c * n + i] + b1[c], 0.f);
+}
+
+// S[k][c] = max_{i >= k} Q[i][c] with its row index (lowest index on ties); S[n] = none
+__global__ __launch_bounds__(256) void proto_suffix_max_kernel(const float* __restrict__ t2c,
+                                                               const int32_t* __restrict__ row_base,
+                                                               const float* __restrict__ b2, int n, int d,
+                                                               float* __restrict__ sval, int32_t* __restrict__ sidx)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const float* Q = t2c + (int64_t)row_base[0] * d;
+    const float bias = b2[c];
+    float best = 0.f;
+    int bi = -1;
+    sval[(int64_t)n * d + c] = 0.f;
+    sidx[(int64_t)n * d + c] = -1;
+#pragma unroll 8
+    for (int i = n - 1; i >= 0; --i) {
+        const float v = Q[(int64_t)i * d + c] + bias;
+        if (bi < 0 || v >= best) {
+            best = v;
+            bi = i;
+        }
+        sval[(int64_t)i * d + c] = best;
+        sidx[(int64_t)i * d + c] = bi;
+    }
+}
+
+// max-pool backward for compact rows: dT2c[off_b + j, c] = adj[b, am, j] * dpool[b,c], j < n_b
+// (zero when the winning row am is a prototype row: it has no edge to a stored row)
+__global__ __launch_bounds__(256) void pool_bwd_gather_compact_kernel(const float* __restrict__ adj,
+                                                                      const float* __restrict__ dpool,
+                                                                      const int32_t* __restrict__ argmax,
+                                                                      const int32_t* __restrict__ meta, int64_t B,
+                                                                      int n, int d, float* __restrict__ dT2)
+{
+    const int64_t b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const int nb = meta[b], off = meta[B + b];
+    const float g = dpool[b * d + c];
+    const int am = argmax[b * d + c];
+    const float* arow = adj + b * n * n + (int64_t)am * n;
+    float* out = dT2 + (int64_t)off * d + c;
+    for (int j = 0; j < nb; ++j) out[(int64_t)j * d] = (am < nb) ? arow[j] * g : 0.f;
+}
+
+// gradient reaching the prototype rows: dQ[i][c] = sum over graphs whose pooled
+// maximum in column c is row i >= n_b.  Stage 1: block (64 columns, one segment
+// of the batch) walks its graphs in order, each thread adding into its own
+// column of an LDS (n x 64) table; stage 2 adds the segments in order and
+// writes the rows at offset R of dT2c.  Ordered: reproducible.
+constexpr int PG_SEG = 8;
+__global__ __launch_bounds__(64) void proto_grad_stage1(const float* __restrict__ dpool,
+                                                        const int32_t* __restrict__ argmax,
+                                                        const int32_t* __restrict__ meta, int64_t B, int n, int d,
+                                                        float* __restrict__ partial)
+{
+    __shared__ float tab[64 * 64];
+    const int tc = threadIdx.x;
+    const int c = blockIdx.x * 64 + tc;
+    const int seg = blockIdx.y;
+    for (int i = 0; i < n; ++i) tab[i * 64 + tc] = 0.f;
+    const int64_t per = (B + PG_SEG - 1) / PG_SEG;
+    const int64_t b0 = seg * per, b1 = min(B, b0 + per);
+    if (c < d) {
+        for (int64_t b = b0; b < b1; ++b) {
+            const int am = argmax[b * d + c];
+            if (am >= meta[b]) tab[am * 64 + tc] += dpool[b * d + c];
+        }
+        for (int i = 0; i < n; ++i) partial[((int64_t)seg * n + i) * d + c] = tab[i * 64 + tc];
+    }
+}
+
+__global__ __launch_bounds__(256) void proto_grad_stage2(const float* __restrict__ partial,
+                                                         const int32_t* __restrict__ row_base, int n, int d,
+                                                         float* __restrict__ dT2c)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    float s = 0.f;
+    for (int k = 0; k < PG_SEG; ++k) s += partial[(int64_t)k * n * d + idx];
+    dT2c[(int64_t)row_base[0] * d + idx] = s;
 }
 
 __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ out,
@@ -374,22 +541,28 @@ size_t colsum_workspace(int64_t rows, int cols)
 
 int colsum(const float* X, int64_t rows, int cols, int ld, float* partial, float* out, hipStream_t s)
 {
+    return colsum_dev(X, rows, nullptr, cols, ld, partial, out, s);
+}
+
+int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int ld, float* partial, float* out,
+               hipStream_t s)
+{
     if (cols == 0) return GTG_OK;
     const int chunk = cs_chunk_rows(rows);
     const int nchunks = (int)((rows + chunk - 1) / chunk);
     const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ld % 4 == 0);
     const dim3 grid((cols + CS_COLS - 1) / CS_COLS, nchunks > 0 ? nchunks : 1);
     if (nchunks <= 1) {
-        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, out);
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, rows_dev, out);
         return check_launch("colsum_kernel");
     }
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, partial);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, rows_dev, partial);
     int rc = check_launch("colsum_kernel");
     if (rc) return rc;
     // second stage: the partials form an (nchunks x cols) matrix; same kernel, one chunk
     const int vec2 = ((reinterpret_cast<uintptr_t>(partial) & 15) == 0) && (cols % 4 == 0);
     hipLaunchKernelGGL(colsum_kernel, dim3((cols + CS_COLS - 1) / CS_COLS, 1), dim3(256), 0, s, partial,
-                       (int64_t)nchunks, cols, cols, nchunks, vec2, out);
+                       (int64_t)nchunks, cols, cols, nchunks, vec2, (const int*)nullptr, out);
     return check_launch("colsum_kernel");
 }
 
@@ -440,6 +613,55 @@ int bce_bwd(const float* out, const float* adj, int64_t B, int n, const float* g
     hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)B), dim3(256), 0, s, out, adj, n, m, gdev,
                        gscale / ((float)B * (float)m), through_sigmoid, dy2);
     return check_launch("bce_bwd_kernel");
+}
+
+int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, hipStream_t s)
+{
+    if (B == 0) return GTG_OK;
+    hipLaunchKernelGGL(graph_extent_kernel, dim3((unsigned)B), dim3(64), 0, s, counts, n, meta);
+    int rc = check_launch("graph_extent_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(graph_offsets_kernel, dim3(1), dim3(256), 0, s, meta, (int)B, n, meta + B);
+    rc = check_launch("graph_offsets_kernel");
+    if (rc || adjc == nullptr) return rc;
+    hipLaunchKernelGGL(adj_compact_kernel, dim3((unsigned)B + 1), dim3(256), 0, s, adj, meta, B, n, adjc);
+    return check_launch("adj_compact_kernel");
+}
+
+int proto_h1(const float* W1, const float* b1, int n, int H, const int32_t* row_base, float* h1c, hipStream_t s)
+{
+    hipLaunchKernelGGL(proto_h1_kernel, dim3((n * H + 255) / 256), dim3(256), 0, s, W1, b1, n, H, row_base, h1c);
+    return check_launch("proto_h1_kernel");
+}
+
+int proto_suffix_max(const float* t2c, const int32_t* row_base, const float* b2, int n, int d, float* sval,
+                     int32_t* sidx, hipStream_t s)
+{
+    hipLaunchKernelGGL(proto_suffix_max_kernel, dim3((d + 255) / 256), dim3(256), 0, s, t2c, row_base, b2, n, d, sval,
+                       sidx);
+    return check_launch("proto_suffix_max_kernel");
+}
+
+int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,
+                            int64_t B, int n, int d, float* dT2, hipStream_t s)
+{
+    if (B == 0 || d == 0) return GTG_OK;
+    hipLaunchKernelGGL(pool_bwd_gather_compact_kernel, dim3((d + 255) / 256, (unsigned)B), dim3(256), 0, s, adj, dpool,
+                       argmax, meta, B, n, d, dT2);
+    return check_launch("pool_bwd_gather_compact_kernel");
+}
+
+size_t proto_grad_workspace(int n, int d) { return (size_t)PG_SEG * n * d * sizeof(float); }
+
+int proto_grad(const float* dpool, const int32_t* argmax, const int32_t* meta, int64_t B, int n, int d, float* partial,
+               float* dT2c, hipStream_t s)
+{
+    hipLaunchKernelGGL(proto_grad_stage1, dim3((d + 63) / 64, PG_SEG), dim3(64), 0, s, dpool, argmax, meta, B, n, d,
+                       partial);
+    int rc = check_launch("proto_grad_stage1");
+    if (rc) return rc;
+    hipLaunchKernelGGL(proto_grad_stage2, dim3((n * d + 255) / 256), dim3(256), 0, s, partial, meta + 2 * B, n, d, dT2c);
+    return check_launch("proto_grad_stage2");
 }
 
 int sigmoid_bwd(const float* out, const float* dout, int64_t total, float* dy, hipStream_t s)

@@ -53,6 +53,14 @@ struct GemmDesc {
     long long strideAux = 0;
     float* pool_val = nullptr;   // (batch, N)
     int32_t* pool_idx = nullptr; // (batch, N)
+    // ragged / device-sized extents (all optional, device pointers)
+    const int* m_dev = nullptr;      // M = min(M, *m_dev): tiles past it exit at once
+    const int* k_dev = nullptr;      // K = min(K, *k_dev)
+    const int* batch_dim = nullptr;  // per batch: M = K = batch_dim[b]
+    const int* batch_off = nullptr;  // per batch: row offset applied to B (off_b) and/or C and aux (off_c)
+    bool off_b = false, off_c = false;
+    const float* proto_val = nullptr;    // EPI_POOL: ((max batch_dim)+1, N) values merged at row batch_dim[b]
+    const int32_t* proto_idx = nullptr;  //           and their row indices (-1 = none)
     // split-K: when splits > 1 the kernel writes `splits` partial slabs of
     // M*N floats into `slabs` and a second kernel sums them in slab order into C
     // (bitwise reproducible; no float atomics).
@@ -72,6 +80,20 @@ int pool_bwd_gather(const float* adj, const float* dpool, const int32_t* argmax,
                     float* dT2, hipStream_t s);
 int colsum(const float* X, int64_t rows, int cols, int ld, float* partial, float* out, hipStream_t s);
 size_t colsum_workspace(int64_t rows, int cols);
+// rows = min(rows, *rows_dev) when rows_dev is given (row count known only on the device)
+int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int ld, float* partial, float* out,
+               hipStream_t s);
+// compact node rows (identity features): meta = [n_b (B) | row offsets (B+1) | R + n], adjc = compact adjacency
+// rows followed by n identity rows (the prototype rows)
+int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, hipStream_t s);
+int proto_h1(const float* W1, const float* b1, int n, int H, const int32_t* row_base, float* h1c, hipStream_t s);
+int proto_suffix_max(const float* t2c, const int32_t* row_base, const float* b2, int n, int d, float* sval,
+                     int32_t* sidx, hipStream_t s);
+int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,
+                            int64_t B, int n, int d, float* dT2, hipStream_t s);
+size_t proto_grad_workspace(int n, int d);
+int proto_grad(const float* dpool, const int32_t* argmax, const int32_t* meta, int64_t B, int n, int d, float* partial,
+               float* dT2c, hipStream_t s);
 int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z,
                float* kl_partial, float* kl_out, hipStream_t s);
 int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const float* eps, const float* kl_scale_dev,

@@ -28,10 +28,13 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 # adjacency
 # ---------------------------------------------------------------------------
-def build_adj(edge_index: torch.Tensor, num_graphs: int, nmax: int, check_edges: bool = False) -> torch.Tensor:
+def build_adj(edge_index: torch.Tensor, num_graphs: int, nmax: int, check_edges: bool = False,
+              return_counts: bool = False):
     """D^-1/2 (C + I) D^-1/2 per graph, (B, nmax, nmax) fp32, from a PyG-style
     batched edge_index (2, E) int64.  With check_edges the error flag is read
-    back (a host sync) and an exception raised if an edge leaves its graph."""
+    back (a host sync) and an exception raised if an edge leaves its graph.
+    With return_counts the raw (B*n*n) int32 edge counts are returned as well
+    (the compact encoder derives each graph's extent from them)."""
     _lib.require_cuda(edge_index)
     ei = edge_index.contiguous()
     if ei.dtype != torch.int64:
@@ -44,7 +47,7 @@ def build_adj(edge_index: torch.Tensor, num_graphs: int, nmax: int, check_edges:
           "gtg_adj_build")
     if check_edges and int(err.item()) != 0:
         raise _lib.GtgError("edge_index holds an edge whose endpoints are out of range or in different graphs")
-    return adj
+    return (adj, counts) if return_counts else adj
 
 
 # ---------------------------------------------------------------------------
@@ -54,7 +57,7 @@ class EncoderFn(torch.autograd.Function):
     """pooled (B, d) = global_max_pool(GCN2(relu(GCN1(x))))."""
 
     @staticmethod
-    def forward(ctx, adj, x, W1, b1, W2, b2):
+    def forward(ctx, adj, x, W1, b1, W2, b2, counts=None):
         L = _lib.lib()
         adj, x, W1, b1, W2, b2 = map(_f32c, (adj, x, W1, b1, W2, b2))
         B, n, _ = adj.shape
@@ -65,6 +68,22 @@ class EncoderFn(torch.autograd.Function):
         if x is not None and tuple(x.shape) != (B * n, f):
             raise _lib.GtgError(f"x must be (B*n, f) = ({B * n}, {f}), got {tuple(x.shape)}")
         dev = adj.device
+        ctx.compact = x is None and counts is not None and f == n
+        if ctx.compact:
+            # identity features: only the rows an edge touches are stored and multiplied
+            meta = torch.empty((2 * B + 2,), dtype=torch.int32, device=dev)
+            adjc = torch.empty((B * n + n, n), dtype=torch.float32, device=dev)
+            h1c = torch.empty((B * n + n, H), dtype=torch.float32, device=dev)
+            pooled = torch.empty((B, d), dtype=torch.float32, device=dev)
+            argmax = torch.empty((B, d), dtype=torch.int32, device=dev)
+            ws = _ws(L.gtg_encoder_compact_fwd_workspace_bytes(B, n, d), dev)
+            check(L.gtg_encoder_compact_fwd(ptr(adj), ptr(counts), ptr(W1), ptr(b1), ptr(W2), ptr(b2), B, n, d,
+                                            ptr(meta), ptr(adjc), ptr(h1c), ptr(pooled), ptr(argmax), ptr(ws),
+                                            ws.numel(), stream_ptr()), "gtg_encoder_compact_fwd")
+            ctx.save_for_backward(adj, adjc, meta, W2, h1c, argmax)
+            ctx.dims = (B, n, f, d)
+            ctx.mark_non_differentiable(argmax)
+            return pooled, argmax
         h1 = torch.empty((B * n, H), dtype=torch.float32, device=dev)
         pooled = torch.empty((B, d), dtype=torch.float32, device=dev)
         argmax = torch.empty((B, d), dtype=torch.int32, device=dev)
@@ -80,21 +99,28 @@ class EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpooled, _dargmax):
         L = _lib.lib()
-        adj, x, W1, W2, h1, argmax = ctx.saved_tensors
         B, n, f, d = ctx.dims
-        dev = adj.device
         dpooled = _f32c(dpooled)
-        dW1 = torch.empty_like(W1)
+        dev = dpooled.device
+        dW1 = torch.empty((2 * d, f), dtype=torch.float32, device=dev)
         db1 = torch.empty((2 * d,), dtype=torch.float32, device=dev)
-        dW2 = torch.empty_like(W2)
+        dW2 = torch.empty((d, 2 * d), dtype=torch.float32, device=dev)
         db2 = torch.empty((d,), dtype=torch.float32, device=dev)
+        if ctx.compact:
+            adj, adjc, meta, W2, h1c, argmax = ctx.saved_tensors
+            ws = _ws(L.gtg_encoder_compact_bwd_workspace_bytes(B, n, d), dev)
+            check(L.gtg_encoder_compact_bwd(ptr(adj), ptr(adjc), ptr(meta), ptr(W2), ptr(h1c), ptr(argmax),
+                                            ptr(dpooled), B, n, d, ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(ws),
+                                            ws.numel(), stream_ptr()), "gtg_encoder_compact_bwd")
+            return None, None, dW1, db1, dW2, db2, None
+        adj, x, W1, W2, h1, argmax = ctx.saved_tensors
         nb = L.gtg_encoder_bwd_workspace_bytes(B, n, f, d, int(x is not None))
         ws = _ws(nb, dev)
         check(L.gtg_encoder_bwd(ptr(adj), ptr(x), ptr(W1), ptr(W2), ptr(h1), ptr(argmax), ptr(dpooled), B, n, f, d,
                                 ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(ws), ws.numel(), stream_ptr()),
               "gtg_encoder_bwd")
         # node features and the adjacency are inputs, not parameters: no gradient
-        return None, None, dW1, db1, dW2, db2
+        return None, None, dW1, db1, dW2, db2, None
 
 
 # ---------------------------------------------------------------------------

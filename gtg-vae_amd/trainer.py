@@ -137,7 +137,9 @@ class GraphVAETrainer:
         self.adj = torch.empty((B, n, n), **f32)
         self.target = torch.empty((B, n, n), **f32)
         self.eps_buf = torch.empty((B, d), **f32)
-        self.h1 = torch.empty((B * n, 2 * d), **f32)
+        self.h1 = torch.empty((B * n + n, 2 * d), **f32)  # compact rows: R real + n prototype rows are valid
+        self.meta = torch.zeros(2 * B + 2, dtype=torch.int32, device=dev)
+        self.adjc = torch.empty((B * n + n, n), **f32)
         self.pooled = torch.empty((B, d), **f32)
         self.argmax = torch.empty((B, d), dtype=torch.int32, device=dev)
         self.mu = torch.empty((B, d), **f32)
@@ -148,7 +150,7 @@ class GraphVAETrainer:
         self.dz = torch.empty((B, d), **f32)
         self.dh = torch.empty((B, d), **f32)
         self.scalars = torch.zeros(2, **f32)  # [recon, kl]
-        nbytes = max(L.gtg_encoder_fwd_workspace_bytes(B, n, f, d, 0), L.gtg_encoder_bwd_workspace_bytes(B, n, f, d, 0),
+        nbytes = max(L.gtg_encoder_compact_fwd_workspace_bytes(B, n, d), L.gtg_encoder_compact_bwd_workspace_bytes(B, n, d),
                      L.gtg_latent_workspace_bytes(B, d), L.gtg_decoder_bwd_workspace_bytes(B, d, hid, m),
                      L.gtg_bce_workspace_bytes(B))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -175,9 +177,13 @@ class GraphVAETrainer:
         ws, wsn = ptr(self.ws), self.ws.numel()
         check(L.gtg_adj_build(ptr(self.ei), self.ei.shape[1], B, n, ptr(self.counts), ptr(self.err), ptr(self.adj),
                               stream), "gtg_adj_build")
-        check(L.gtg_encoder_fwd(ptr(self.adj), None, ptr(p["encoder.conv1.lin.weight"]), ptr(p["encoder.conv1.bias"]),
-                                ptr(p["encoder.conv2.lin.weight"]), ptr(p["encoder.conv2.bias"]), B, n, f, d,
-                                ptr(self.h1), ptr(self.pooled), ptr(self.argmax), ws, wsn, stream), "gtg_encoder_fwd")
+        # meta is carved per call: [n_b (B) | offsets (B+1) | R + n] for THIS batch size
+        meta = self.meta[: 2 * B + 2]
+        check(L.gtg_encoder_compact_fwd(ptr(self.adj), ptr(self.counts), ptr(p["encoder.conv1.lin.weight"]),
+                                        ptr(p["encoder.conv1.bias"]), ptr(p["encoder.conv2.lin.weight"]),
+                                        ptr(p["encoder.conv2.bias"]), B, n, d, ptr(meta), ptr(self.adjc), ptr(self.h1),
+                                        ptr(self.pooled), ptr(self.argmax), ws, wsn, stream),
+              "gtg_encoder_compact_fwd")
         check(L.gtg_latent_fwd(ptr(self.pooled), ptr(p["zg_mu.weight"]), ptr(p["zg_mu.bias"]), ptr(p["zg_var.weight"]),
                                ptr(p["zg_var.bias"]), ptr(self.eps_buf), B, d, ptr(self.mu), ptr(self.logvar),
                                ptr(self.z), self.scalars[1:].data_ptr(), ws, wsn, stream), "gtg_latent_fwd")
@@ -200,11 +206,11 @@ class GraphVAETrainer:
                                ptr(g["zg_var.bias"]), ptr(self.dh), ws, wsn, stream), "gtg_latent_bwd")
         if update and self.world > 1:
             self.buckets.reduce(0)  # decoder + latent gradients travel while the encoder's backward runs
-        check(L.gtg_encoder_bwd(ptr(self.adj), None, ptr(p["encoder.conv1.lin.weight"]),
-                                ptr(p["encoder.conv2.lin.weight"]), ptr(self.h1), ptr(self.argmax), ptr(self.dh), B, n,
-                                f, d, ptr(g["encoder.conv1.lin.weight"]), ptr(g["encoder.conv1.bias"]),
-                                ptr(g["encoder.conv2.lin.weight"]), ptr(g["encoder.conv2.bias"]), ws, wsn, stream),
-              "gtg_encoder_bwd")
+        check(L.gtg_encoder_compact_bwd(ptr(self.adj), ptr(self.adjc), ptr(meta), ptr(p["encoder.conv2.lin.weight"]),
+                                        ptr(self.h1), ptr(self.argmax), ptr(self.dh), B, n, d,
+                                        ptr(g["encoder.conv1.lin.weight"]), ptr(g["encoder.conv1.bias"]),
+                                        ptr(g["encoder.conv2.lin.weight"]), ptr(g["encoder.conv2.bias"]), ws, wsn,
+                                        stream), "gtg_encoder_compact_bwd")
         if update:
             if self.world > 1:
                 self.buckets.reduce(1)

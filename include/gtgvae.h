@@ -97,6 +97,27 @@ int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const flo
                     const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int f, int d, float* dW1,
                     float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, void* stream);
 
+/* Encoder on compact node rows, identity node features only (x = I_n, f == n).
+ * Rows [0, n_b) of graph b are stored back to back (n_b = 1 + the highest node
+ * index a non-self edge touches, R rows in all); the rows past n_b are
+ * identical in every graph, so they are stored once, as n "prototype" rows
+ * right after the real ones (n extra nodes whose adjacency row is the unit
+ * vector), and merged into the max-pool as a suffix maximum.  Results equal
+ * gtg_encoder_fwd/bwd with x = NULL; the row-proportional GEMMs shrink from
+ * B*n to R + n rows.
+ *   counts  (B*n*n) int32: the scratch gtg_adj_build filled on this stream
+ *   meta    (2B+2)  int32 out: n_b per graph, B+1 exclusive row offsets (last = R), R + n
+ *   adjc    (B*n + n, n) out: compact adjacency rows, then the n unit rows
+ *   h1c     (B*n + n, 2d) out: first R + n rows valid */
+size_t gtg_encoder_compact_fwd_workspace_bytes(int64_t num_graphs, int n, int d);
+int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float* W1, const float* b1, const float* W2,
+                            const float* b2, int64_t num_graphs, int n, int d, int32_t* meta, float* adjc, float* h1c,
+                            float* pooled, int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+size_t gtg_encoder_compact_bwd_workspace_bytes(int64_t num_graphs, int n, int d);
+int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* meta, const float* W2, const float* h1c,
+                            const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int d, float* dW1,
+                            float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- latent head ---------------------------------------------------------
  * Replaces zg_mu / zg_var (src/gtvae.py:25-26,108-109), reparameterize
  * (src/gtvae.py:33-37, eps supplied by the caller) and loss_kl

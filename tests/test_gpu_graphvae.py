@@ -74,12 +74,50 @@ def test_encoder_forward_backward(B, N, d, hid, identity_x):
 
     names = ["encoder.conv1.lin.weight", "encoder.conv1.bias", "encoder.conv2.lin.weight", "encoder.conv2.bias"]
     gp = [p[k].detach().cuda().requires_grad_(True) for k in names]
-    adj = Fn.build_adj(batch.edge_index.cuda(), B, N)
-    got, argmax = Fn.EncoderFn.apply(adj, None if x is None else x.cuda(), *gp)
+    adj, counts = Fn.build_adj(batch.edge_index.cuda(), B, N, return_counts=True)
+    got, argmax = Fn.EncoderFn.apply(adj, None if x is None else x.cuda(), *gp, counts)
     assert _relerr(got, want) < 1e-5
     (got * up.cuda()).sum().backward()
     for k, t in zip(names, gp):
         assert _relerr(t.grad, p[k].grad) < 1e-4, k
+
+
+@pytest.mark.parametrize("N,d", [(10, 16), (64, 64)])
+def test_compact_encoder_edge_cases(N, d):
+    """Compact-row encoder (identity features) on awkward graphs: no edges at all,
+    one directed edge, edges that touch only high node indices (untouched nodes
+    in between), a full chain; forward and backward against the oracle and
+    against the dense path fed an explicit identity matrix."""
+    from gtg_vae_amd import functional as Fn
+    from oracle import graphvae_oracle as O
+
+    B = 6
+    edges = []
+    edges += [(1 * N + 0, 1 * N + 1)]                                       # graph 1: one directed edge
+    edges += [(2 * N + N - 3, 2 * N + N - 1), (2 * N + N - 1, 2 * N + N - 3)]  # graph 2: only high indices
+    edges += [(3 * N + i, 3 * N + i + 1) for i in range(N - 1)]              # graph 3: chain, one direction
+    edges += [(3 * N + i + 1, 3 * N + i) for i in range(N - 1)]
+    edges += [(4 * N + 2, 4 * N + 2), (4 * N + 0, 4 * N + 0)]                # graph 4: self loops only
+    edges += [(5 * N + 0, 5 * N + 4)] * 3 + [(5 * N + 4, 5 * N + 0)]          # graph 5: multiplicity
+    ei = torch.tensor(edges, dtype=torch.long).t().contiguous()             # graph 0: nothing
+    p = {k: v.clone().requires_grad_(True) for k, v in _oracle_params(N, d, 16, seed=12).items()}
+    want = O.encode(p, None, ei, B, N)
+    up = torch.randn(B, d, generator=torch.Generator().manual_seed(4))
+    (want * up).sum().backward()
+    names = ["encoder.conv1.lin.weight", "encoder.conv1.bias", "encoder.conv2.lin.weight", "encoder.conv2.bias"]
+    adj, counts = Fn.build_adj(ei.cuda(), B, N, return_counts=True)
+    outs = []
+    for compact in (True, False):
+        gp = [p[k].detach().cuda().requires_grad_(True) for k in names]
+        x = None if compact else torch.eye(N).repeat(B, 1).cuda()
+        got, am = Fn.EncoderFn.apply(adj, x, *gp, counts if compact else None)
+        assert _relerr(got, want) < 1e-5, compact
+        (got * up.cuda()).sum().backward()
+        for k, t in zip(names, gp):
+            assert _relerr(t.grad, p[k].grad) < 1e-4, (compact, k)
+        outs.append((got.detach().clone(), am.clone()))
+    assert torch.equal(outs[0][1], outs[1][1])          # same winning rows in both paths
+    assert _relerr(outs[0][0], outs[1][0]) < 1e-6
 
 
 @pytest.mark.parametrize("B,d", [(8, 32), (256, 256), (5, 7)])
