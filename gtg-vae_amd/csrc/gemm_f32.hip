@@ -15,13 +15,13 @@
 // per 4 MFMAs; A and B use the same permutation, so the product is unchanged.
 #include "gtg_internal.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace gtg {
 
 namespace {
 
 constexpr int BK = 32;
-constexpr int NTHREADS = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -66,11 +66,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // The +4 float pad keeps 16-byte alignment and makes both the ds_write_b128
 // of staging and the ds_read_b128 / ds_read_b32 of the fragment reads
 // bank-conflict-free.
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int NTHREADS>
 struct Tile {
     static constexpr int LD = KC ? (BK + 4) : (ROWS + 4);
     static constexpr int SIZE = KC ? ROWS * LD : BK * LD;
     static constexpr int NV = ROWS * BK / 4 / NTHREADS;
+    static_assert(NV >= 1 && NV * NTHREADS * 4 == ROWS * BK, "tile must split evenly over the staging threads");
     static constexpr int V4 = ROWS / 4;
 
     // Interior tiles with 16-byte-aligned rows take the branch-free path: NV
@@ -163,26 +164,36 @@ struct Tile {
     }
 };
 
-template <int BM, int BN, int WAVES_M, bool AKC, bool BKC>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
+// WAVES_M x WAVES_N waves share one BM x BN tile; KG such wave groups split the
+// block's K range between them (each with its own LDS buffers and its own
+// loads) and their accumulators are summed through LDS, in group order, before
+// the epilogue.  KG > 1 shortens the dependent load -> LDS -> MFMA chain of
+// short-and-narrow GEMMs (batch-sized M, K of a few hundred) that have too few
+// tiles to hide it behind other blocks.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const KArgs a)
 {
-    using TA = Tile<BM, AKC>;
-    using TB = Tile<BN, BKC>;
-    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int GT = 64 * WAVES_M * WAVES_N;  // threads of one wave group
+    constexpr int GW = WAVES_M * WAVES_N;
+    using TA = Tile<BM, AKC, GT>;
+    using TB = Tile<BN, BKC, GT>;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 
-    // operand double buffers; reused by the epilogue to stage the accumulators
+    // operand double buffers per wave group; reused by the epilogue to stage the accumulators
     constexpr int LDC = WTN + 4;
-    constexpr int SMEM_MAIN = 2 * (TA::SIZE + TB::SIZE), SMEM_EPI = 4 * WTM * LDC;
+    constexpr int SMEM_GROUP = 2 * (TA::SIZE + TB::SIZE);
+    constexpr int SMEM_MAIN = KG * SMEM_GROUP, SMEM_EPI = KG * GW * WTM * LDC;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
-    float* const sA0 = smem;
-    float* const sB0 = smem + TA::SIZE;
-    float* const sA1 = smem + TA::SIZE + TB::SIZE;
+
+    const int kg = (KG > 1) ? (int)threadIdx.x / GT : 0;
+    const int tid = (KG > 1) ? (int)threadIdx.x % GT : (int)threadIdx.x;
+    float* const sA0 = smem + kg * SMEM_GROUP;
+    float* const sB0 = sA0 + TA::SIZE;
+    float* const sA1 = sA0 + TA::SIZE + TB::SIZE;
     float* const sB1 = sA1 + TA::SIZE;
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = (wave / WAVES_N) * WTM, wn = (wave % WAVES_N) * WTN;
@@ -221,8 +232,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
     // split-K over the effective depth, so that every split has an equal share
     int kps = a.k_per_split;
     if (a.k_dev && a.splits > 1) kps = ((Kr + a.splits - 1) / a.splits + BK - 1) / BK * BK;
-    const int k_begin = split * kps;
-    const int k_end = min(Kr, k_begin + kps);
+    int k_begin = split * kps;
+    int k_end = min(Kr, k_begin + kps);
+    // every wave group runs the same number of iterations (block-wide barriers); a group whose share is
+    // empty or short multiplies zero tiles
+    int nk = (k_end - k_begin + BK - 1) / BK;
+    if (KG > 1) {
+        nk = (nk + KG - 1) / KG;
+        k_begin += kg * nk * BK;
+        k_end = min(k_end, k_begin + nk * BK);
+    }
     const float* __restrict__ A = a.A + batch * a.strideA;
     const float* __restrict__ B = a.B + batch * a.strideB + (a.off_b ? row_off * a.ldb : 0);
 
@@ -240,7 +259,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
     // fetch of tile kt+2, so the staging traffic sits in the shadow of the
     // MFMA stream and a global load has a whole iteration to land.
     f32x4 ra[TA::NV], rb[TB::NV];
-    const int nk = (k_end - k_begin + BK - 1) / BK;
     if (nk > 0) {
         TA::fetch(ra, A, a.lda, m0, Mr, k_begin, k_end, a.vecA, tid);
         TB::fetch(rb, B, a.ldb, n0, a.N, k_begin, k_end, a.vecB, tid);
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
     // ---- epilogue.  Accumulator register e of lane (r,h) is element
     // (row = (e&3) + 8*(e>>2) + 4h, col = r) of its 32x32 tile.
     if (a.epi == EPI_POOL) {
-        if (WAVES_M == 1) {
+        if (WAVES_M == 1 && KG == 1) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn + 32 * j + r;
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
     // stores -- and the aux / C loads of the mask and accumulate epilogues --
     // are whole 16-byte row segments, 4 or 8 full rows per wave instruction,
     // instead of one dword per lane per accumulator register.
-    float* sC = smem + wave * (WTM * LDC);
+    float* sC = smem + (kg * GW + wave) * (WTM * LDC);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -359,6 +377,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
             for (int e = 0; e < 16; ++e)
                 sC[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + 32 * j + r] = acc[i][j][e];
     __syncthreads();
+    if (KG > 1 && kg != 0) return;  // group 0 sums the groups' tiles below
 
     constexpr int LPR = WTN / 4;   // lanes per row
     constexpr int RPI = 64 / LPR;  // rows per wave instruction
@@ -399,6 +418,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const KArgs a)
         const int lrow = it * RPI + rsub;
         const int grow = m0 + wm + lrow;
         f32x4 v = *reinterpret_cast<const f32x4*>(&sC[lrow * LDC + c4 * 4]);
+#pragma unroll
+        for (int g = 1; g < KG; ++g) v += *reinterpret_cast<const f32x4*>(&sC[g * GW * WTM * LDC + lrow * LDC + c4 * 4]);
         if (grow >= Mr || gcol >= a.N) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -436,7 +457,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *dst = accumulate ? (*dst + s) : s;
 }
 
-enum TileCfg { CFG_128, CFG_64x128, CFG_64 };
+enum TileCfg { CFG_128, CFG_64x128, CFG_64, CFG_64_K2, CFG_32_K4, CFG_COUNT };
+
+// Experiment hook: GTG_GEMM_SMALL=0..2 forces the configuration used for GEMMs with few tiles
+// (0 = 64x64, 1 = 64x64 with two K groups, 2 = 32x32 with four K groups).
+inline int small_override()
+{
+    static const int v = [] {
+        const char* e = getenv("GTG_GEMM_SMALL");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
+}
 
 inline TileCfg pick_cfg(int M, int N, int K, int batch, int epi)
 {
@@ -446,7 +478,15 @@ inline TileCfg pick_cfg(int M, int N, int K, int batch, int epi)
     if (t128 >= 192) return CFG_128;
     // short-and-wide weight-gradient shapes: the big tile still fills the chip once K is split
     if (batch == 1 && M >= 128 && N >= 128 && t128 * (K / 1024) >= 192) return CFG_128;
-    return CFG_64;
+    const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+    const int ov = small_override();
+    if (ov == 0) return CFG_64;
+    if (ov == 1) return K >= 128 ? CFG_64_K2 : CFG_64;
+    if (ov == 2) return (K >= 256 && t64 <= 256) ? CFG_32_K4 : (K >= 128 ? CFG_64_K2 : CFG_64);
+    if (ov == 3) return K >= 256 ? CFG_32_K4 : CFG_64;
+    // few tiles: 32x32 tiles put one on every CU and four wave groups quarter the dependent K chain
+    if (K >= 256 && t64 <= 256) return CFG_32_K4;
+    return K >= 128 ? CFG_64_K2 : CFG_64;
 }
 
 inline void cfg_dims(TileCfg c, int& bm, int& bn)
@@ -454,19 +494,21 @@ inline void cfg_dims(TileCfg c, int& bm, int& bn)
     switch (c) {
         case CFG_128: bm = 128; bn = 128; break;
         case CFG_64x128: bm = 64; bn = 128; break;
+        case CFG_32_K4: bm = 32; bn = 32; break;
         default: bm = 64; bn = 64; break;
     }
 }
 
-template <int BM, int BN, int WAVES_M>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KG>
 int launch_cfg(const KArgs& k, bool akc, bool bkc, int grid, hipStream_t s)
 {
+    const dim3 block(64 * WAVES_M * WAVES_N * KG);
     if (akc && bkc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, true, true>), dim3(grid), dim3(NTHREADS), 0, s, k);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, KG, true, true>), dim3(grid), block, 0, s, k);
     else if (akc && !bkc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, true, false>), dim3(grid), dim3(NTHREADS), 0, s, k);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, KG, true, false>), dim3(grid), block, 0, s, k);
     else if (!akc && !bkc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, false, false>), dim3(grid), dim3(NTHREADS), 0, s, k);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, KG, false, false>), dim3(grid), block, 0, s, k);
     else
         return set_error(GTG_ERR_UNSUPPORTED, "gemm: A M-contiguous with B K-contiguous is not instantiated");
     return check_launch("gemm_kernel");
@@ -570,10 +612,12 @@ int gemm(const GemmDesc& d, hipStream_t s)
     const long long grid = (long long)k.tiles_m * k.tiles_n * splits * d.batch;
     if (grid > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "gemm: grid too large");
 
-    static const char* const kNames[3][3] = {
+    static const char* const kNames[CFG_COUNT][3] = {
         {"gemm128_nt", "gemm128_nn", "gemm128_tn"},
         {"gemm64x128_nt", "gemm64x128_nn", "gemm64x128_tn"},
-        {"gemm64_nt", "gemm64_nn", "gemm64_tn"}};
+        {"gemm64_nt", "gemm64_nn", "gemm64_tn"},
+        {"gemm64k2_nt", "gemm64k2_nn", "gemm64k2_tn"},
+        {"gemm32k4_nt", "gemm32k4_nn", "gemm32k4_tn"}};
     const int lay = d.a_kc ? (d.b_kc ? 0 : 1) : 2;
     // a launch whose row count (":m"), depth (":k") or per-graph extent (":g") is read on the device is tagged so:
     // the dimensions recorded with it are then upper bounds, not the work done
@@ -582,9 +626,11 @@ int gemm(const GemmDesc& d, hipStream_t s)
     ProfScope prof(s, tag, (long long)d.M * d.batch, d.N, d.K);
     int rc;
     switch (cfg) {
-        case CFG_128: rc = launch_cfg<128, 128, 2>(k, d.a_kc, d.b_kc, (int)grid, s); break;
-        case CFG_64x128: rc = launch_cfg<64, 128, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;
-        default: rc = launch_cfg<64, 64, 2>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        case CFG_128: rc = launch_cfg<128, 128, 2, 2, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        case CFG_64x128: rc = launch_cfg<64, 128, 1, 4, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        case CFG_64_K2: rc = launch_cfg<64, 64, 2, 2, 2>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        case CFG_32_K4: rc = launch_cfg<32, 32, 1, 1, 4>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        default: rc = launch_cfg<64, 64, 2, 2, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;
     }
     if (rc != GTG_OK) return rc;
     if (splits > 1) {

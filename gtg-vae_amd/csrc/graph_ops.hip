@@ -38,6 +38,20 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm /* >= 4 floats
 // adjacency: counts[b][i][j] = #edges (src=j -> dst=i), self loops dropped.
 // Integer atomics: order-independent, exact.
 // ---------------------------------------------------------------------------
+// The clear is a kernel of this library rather than a memset so that a step
+// captured in a HIP graph replays it as an ordinary kernel node.
+__global__ __launch_bounds__(256) void adj_clear_kernel(int32_t* __restrict__ counts, int64_t total,
+                                                        int32_t* __restrict__ err)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i == 0) *err = 0;
+    if (i + 3 < total) {
+        *reinterpret_cast<int4*>(counts + i) = make_int4(0, 0, 0, 0);
+    } else {
+        for (int64_t j = i; j < total; ++j) counts[j] = 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void adj_count_kernel(const int64_t* __restrict__ ei, int64_t E, int64_t B, int n,
                                                         int32_t* __restrict__ counts, int32_t* __restrict__ err)
 {
@@ -508,9 +522,10 @@ __global__ __launch_bounds__(256) void edge_prf_kernel(const int32_t* __restrict
 // ===========================================================================
 int adj_count(const int64_t* ei, int64_t E, int64_t B, int n, int32_t* counts, int32_t* err, hipStream_t s)
 {
-    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)B * n * n, s) != hipSuccess ||
-        hipMemsetAsync(err, 0, sizeof(int32_t), s) != hipSuccess)
-        return set_error(GTG_ERR_LAUNCH, "adj_count: memset failed");
+    const int64_t total = B * n * n;
+    if (reinterpret_cast<uintptr_t>(counts) & 15) return set_error(GTG_ERR_INVALID, "adj_count: counts must be 16-byte aligned");
+    hipLaunchKernelGGL(adj_clear_kernel, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, s, counts, total, err);
+    if (const int rc = check_launch("adj_clear_kernel")) return rc;
     if (E == 0) return GTG_OK;
     hipLaunchKernelGGL(adj_count_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, ei, E, B, n, counts, err);
     return check_launch("adj_count_kernel");

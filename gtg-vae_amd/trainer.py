@@ -171,9 +171,12 @@ class GraphVAETrainer:
         self._B = B
 
     # ------------------------------------------------------------------ the step
-    def _launch(self, B: int, update: bool, stream: int, backward: bool = True):
-        L, n, d, hid, m, f = self.L, self.n, self.d, self.hid, self.m, self.f
-        p, g = self.p, self.g
+    # The step is three runs of launches with the two gradient all-reduces between
+    # them; each run can be replayed as a HIP graph while the collectives stay
+    # ordinary stream work.
+    def _seg_forward(self, B: int, stream: int):
+        L, n, d, hid, m = self.L, self.n, self.d, self.hid, self.m
+        p = self.p
         ws, wsn = ptr(self.ws), self.ws.numel()
         check(L.gtg_adj_build(ptr(self.ei), self.ei.shape[1], B, n, ptr(self.counts), ptr(self.err), ptr(self.adj),
                               stream), "gtg_adj_build")
@@ -192,9 +195,12 @@ class GraphVAETrainer:
                                 ptr(self.y1), ptr(self.out), stream), "gtg_decoder_fwd")
         check(L.gtg_bce_loss_fwd(ptr(self.out), ptr(self.target), B, n, self.scalars.data_ptr(), ws, wsn, stream),
               "gtg_bce_loss_fwd")
-        if not backward:
-            return
-        # ---- backward ---------------------------------------------------------
+
+    def _seg_head_backward(self, B: int, stream: int):
+        """Decoder and latent head: their gradients (bucket 0) are final after this."""
+        L, n, d, hid, m = self.L, self.n, self.d, self.hid, self.m
+        p, g = self.p, self.g
+        ws, wsn = ptr(self.ws), self.ws.numel()
         check(L.gtg_decoder_bwd(ptr(self.z), ptr(p["decoder.decode_1.weight"]), ptr(p["decoder.decode_2.weight"]),
                                 ptr(self.y1), ptr(self.out), None, ptr(self.target), n, 1.0, None, B, d, hid, m,
                                 ptr(g["decoder.decode_1.weight"]), ptr(g["decoder.decode_1.bias"]),
@@ -204,48 +210,93 @@ class GraphVAETrainer:
                                ptr(self.logvar), ptr(self.eps_buf), ptr(self.dz), 1.0, ptr(self.kl_w_dev), B, d,
                                ptr(g["zg_mu.weight"]), ptr(g["zg_mu.bias"]), ptr(g["zg_var.weight"]),
                                ptr(g["zg_var.bias"]), ptr(self.dh), ws, wsn, stream), "gtg_latent_bwd")
-        if update and self.world > 1:
-            self.buckets.reduce(0)  # decoder + latent gradients travel while the encoder's backward runs
+
+    def _seg_encoder_backward(self, B: int, stream: int):
+        L, n, d = self.L, self.n, self.d
+        p, g = self.p, self.g
+        meta = self.meta[: 2 * B + 2]
         check(L.gtg_encoder_compact_bwd(ptr(self.adj), ptr(self.adjc), ptr(meta), ptr(p["encoder.conv2.lin.weight"]),
                                         ptr(self.h1), ptr(self.argmax), ptr(self.dh), B, n, d,
                                         ptr(g["encoder.conv1.lin.weight"]), ptr(g["encoder.conv1.bias"]),
-                                        ptr(g["encoder.conv2.lin.weight"]), ptr(g["encoder.conv2.bias"]), ws, wsn,
-                                        stream), "gtg_encoder_compact_bwd")
-        if update:
-            if self.world > 1:
-                self.buckets.reduce(1)
-                self.buckets.finish()
-            check(L.gtg_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                                  self.numel, ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps,
-                                  self.buckets.scale, stream), "gtg_adam_step")
+                                        ptr(g["encoder.conv2.lin.weight"]), ptr(g["encoder.conv2.bias"]), ptr(self.ws),
+                                        self.ws.numel(), stream), "gtg_encoder_compact_bwd")
+
+    def _seg_adam(self, stream: int):
+        check(self.L.gtg_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                   self.numel, ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps,
+                                   self.buckets.scale, stream), "gtg_adam_step")
+
+    def _segments(self, B: int, update: bool, backward: bool = True):
+        """The step as a list of callables(stream), with None where an all-reduce goes."""
+        segs = [lambda st: (self._seg_forward(B, st), backward and self._seg_head_backward(B, st))]
+        if backward:
+            segs += [None, lambda st: self._seg_encoder_backward(B, st)]
+            if update:
+                segs += [None, lambda st: self._seg_adam(st)]
+        return segs
+
+    def _run_segments(self, runners, update: bool):
+        """Run the step's segments in order; the i-th gap between them carries the
+        all-reduce of gradient bucket i (decoder + latent head first, so that it
+        travels while the encoder's backward runs)."""
+        bucket = 0
+        last = len(runners) - 1
+        for i, run in enumerate(runners):
+            if run is None:
+                if update and self.world > 1:
+                    self.buckets.reduce(bucket)
+                    if i == last - 1:   # the gap before the optimiser: all gradients must have arrived
+                        self.buckets.finish()
+                bucket += 1
+            else:
+                run()
+
+    def _launch(self, B: int, update: bool, stream: int, backward: bool = True):
+        segs = self._segments(B, update, backward)
+        self._run_segments([None if f is None else (lambda f=f: f(stream)) for f in segs], update)
 
     def set_kl_weight(self, kl_w: float):
         self.kl_w_dev.fill_(float(kl_w))
 
     def run_loaded(self, update: bool = True, use_graph: bool = False):
-        """One step on the batch already in the static buffers."""
+        """One step on the batch already in the static buffers.  With
+        ``use_graph`` the launches between the all-reduces are replayed as HIP
+        graphs (captured on first use for this batch size)."""
         B = self._B
-        if use_graph and self.world == 1:
+        if use_graph:
             key = (B, update, self.ei.shape[1])
             if self._graph is None or self._graph_key != key:
-                # warm up outside capture, then capture the whole step as one HIP graph
-                side = torch.cuda.Stream(device=self.dev)
-                side.wait_stream(torch.cuda.current_stream(self.dev))
-                snap = (self.flat_p.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
-                with torch.cuda.stream(side):
-                    self._launch(B, update, side.cuda_stream)
-                torch.cuda.current_stream(self.dev).wait_stream(side)
-                self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
-                    self._launch(B, update, torch.cuda.current_stream(self.dev).cuda_stream)
-                # the warm-up run advanced the optimiser once: roll it back
-                self.flat_p.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
-                self.adam_state.copy_(snap[3])
+                self._capture(B, update)
                 self._graph_key = key
-            self._graph.replay()
+            self._run_segments([None if g is None else g.replay for g in self._graph], update)
         else:
             self._launch(B, update, torch.cuda.current_stream(self.dev).cuda_stream)
         return {"recon": self.scalars[0], "kl": self.scalars[1]}
+
+    def _capture(self, B: int, update: bool):
+        segs = self._segments(B, update)
+        cur = torch.cuda.current_stream(self.dev)
+        # warm up outside capture (no collectives: the optimiser state is rolled back below)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(cur)
+        snap = (self.flat_p.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
+        with torch.cuda.stream(side):
+            for f in segs:
+                if f is not None:
+                    f(side.cuda_stream)
+        cur.wait_stream(side)
+        graphs = []
+        for f in segs:
+            if f is None:
+                graphs.append(None)
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                f(torch.cuda.current_stream(self.dev).cuda_stream)
+            graphs.append(g)
+        self.flat_p.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
+        self.adam_state.copy_(snap[3])
+        self._graph = graphs
 
     def step(self, batch: GraphBatch, eps: torch.Tensor, kl_w: float = 1.0, update: bool = True,
              use_graph: bool = False):

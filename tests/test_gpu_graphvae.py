@@ -250,20 +250,26 @@ def test_step_is_bitwise_deterministic_and_graph_replay_matches():
     from gtg_vae_amd.data import synth_graph_batch
     from gtg_vae_amd.trainer import GraphVAETrainer
 
-    B, N, d, hid = 32, 32, 64, 128
-    params = _oracle_params(N, d, hid, seed=9)
-    batch = synth_graph_batch(B, N, seed=77).to("cuda")
-    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(5)).cuda()
-    runs = []
-    for use_graph in (False, False, True):
-        tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params)
-        for _ in range(3):
-            res = tr.step(batch, eps, kl_w=0.5, update=True, use_graph=use_graph)
-        torch.cuda.synchronize()
-        runs.append((tr.flat_p.clone(), tr.flat_g.clone(), res["recon"].item(), res["kl"].item()))
-    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
-    assert torch.equal(runs[0][0], runs[2][0]) and torch.equal(runs[0][1], runs[2][1])
-    assert runs[0][2:] == runs[1][2:] == runs[2][2:]
+    # the second shape is large enough that every buffer clear inside the step spans many blocks
+    for B, N, d, hid in ((32, 32, 64, 128), (256, 64, 64, 64)):
+        params = _oracle_params(N, d, hid, seed=9)
+        # different batches (and edge counts) from step to step: a replayed graph must pick up the new inputs
+        batches = [synth_graph_batch(B, N, seed=77 + i).to("cuda") for i in range(3)]
+        eps = [torch.randn(B, d, generator=torch.Generator().manual_seed(5 + i)).cuda() for i in range(3)]
+        max_e = max(b.edge_index.shape[1] for b in batches)
+        runs = []
+        for use_graph in (False, False, True):
+            tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params, max_batch=B, max_edges=max_e)
+            trace = []
+            for i in range(5):
+                res = tr.step(batches[i % 3], eps[i % 3], kl_w=0.5, update=True, use_graph=use_graph)
+                trace.append((res["recon"].item(), res["kl"].item()))
+                assert tr.edges_ok()
+            torch.cuda.synchronize()
+            runs.append((tr.flat_p.clone(), tr.flat_g.clone(), trace))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        assert torch.equal(runs[0][0], runs[2][0]) and torch.equal(runs[0][1], runs[2][1])
+        assert runs[0][2] == runs[1][2] == runs[2][2]
 
 
 def test_loss_report_precision_recall_matches_oracle():
