@@ -51,6 +51,8 @@ _SIGS = {
     "gtg_adam_step": (c_int, [_P] * 4 + [c_int64, _P, c_float, c_float, c_float, c_float, c_float, _P]),
     "gtg_gemm_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, c_int, _P, c_int, _P, c_size_t, _P]),
     "gtg_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gtg_gemm_rows_workspace_bytes": (c_size_t, []),
+    "gtg_gemm_f32_rows": (c_int, [_P] * 3 + [c_int] * 8 + [_P, c_int, _P, c_int, _P, _P, c_size_t, _P]),
 }
 
 EXPORTS = tuple(_SIGS)

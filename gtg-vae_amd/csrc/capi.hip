@@ -382,15 +382,21 @@ int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const flo
 // path, with the row-proportional GEMMs shrunk to the real rows.
 // ---------------------------------------------------------------------------
 struct EncCFwdWs {
-    float *t2c, *sval;
-    int32_t* sidx;
+    float *t2c, *sval, *tail;
+    int32_t *sidx, *tail_cnt;
+    size_t tail_cnt_count;
 };
 
 static void enc_cfwd_layout(Carver& c, int64_t B, int n, int d, EncCFwdWs* w)
 {
+    size_t tb, cb;
+    gemm_tail_workspace(&tb, &cb);
     w->t2c = c.take<float>((size_t)(B * n + n) * d);
     w->sval = c.take<float>((size_t)(n + 1) * d);
     w->sidx = c.take<int32_t>((size_t)(n + 1) * d);
+    w->tail = reinterpret_cast<float*>(c.take<char>(tb));
+    w->tail_cnt = reinterpret_cast<int32_t*>(c.take<char>(cb));
+    w->tail_cnt_count = cb / sizeof(int32_t);
 }
 
 size_t gtg_encoder_compact_fwd_workspace_bytes(int64_t num_graphs, int n, int d)
@@ -420,6 +426,7 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float
     const int32_t* real_rows = meta + 2 * B;      // R
     const int32_t* all_rows = meta + 2 * B + 1;   // R + n
 
+    GTG_TRY(clear_i32(w.tail_cnt, (int64_t)w.tail_cnt_count, s));
     GTG_TRY(graph_meta(counts, adj, B, n, meta, adjc, s));
     GemmDesc g;
     // H1c[off_b + i] = relu(A_b[:n_b,:n_b] * W1^T[:n_b] + b1)
@@ -436,6 +443,7 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float
     g = GemmDesc();
     g.A = h1c; g.lda = H; g.B = W2; g.ldb = H; g.C = w.t2c; g.ldc = d;
     g.M = rows; g.N = d; g.K = H; g.m_dev = all_rows;
+    g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
     GTG_TRY(gemm(g, s));
     // suffix maxima (+ b2) of the prototype rows over the row index
     GTG_TRY(proto_suffix_max(w.t2c, real_rows, b2, n, d, w.sval, w.sidx, s));
@@ -451,7 +459,9 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float
 }
 
 struct EncCBwdWs {
-    float *dT2c, *dZ1c, *pg, *cs, *slabs;
+    float *dT2c, *dZ1c, *pg, *cs, *slabs, *tail;
+    int32_t* tail_cnt;
+    size_t tail_cnt_count;
 };
 
 static void enc_cbwd_layout(Carver& c, int64_t B, int n, int d, EncCBwdWs* w)
@@ -464,6 +474,11 @@ static void enc_cbwd_layout(Carver& c, int64_t B, int n, int d, EncCBwdWs* w)
     w->cs = reinterpret_cast<float*>(c.take<char>(max2(colsum_workspace(B, d), colsum_workspace((int64_t)rows, H))));
     w->slabs = reinterpret_cast<float*>(
         c.take<char>(max2(gemm_splitk_workspace(d, H, (int)rows, 1), gemm_splitk_workspace(H, n, (int)rows, 1))));
+    size_t tb, cb;
+    gemm_tail_workspace(&tb, &cb);
+    w->tail = reinterpret_cast<float*>(c.take<char>(tb));
+    w->tail_cnt = reinterpret_cast<int32_t*>(c.take<char>(cb));
+    w->tail_cnt_count = cb / sizeof(int32_t);
 }
 
 size_t gtg_encoder_compact_bwd_workspace_bytes(int64_t num_graphs, int n, int d)
@@ -489,6 +504,7 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_encoder_compact_bwd: workspace too small");
     const int32_t* all_rows = meta + 2 * B + 1;  // R + n
 
+    GTG_TRY(clear_i32(w.tail_cnt, (int64_t)w.tail_cnt_count, s));
     // dT2c: real rows from the max-pool routing, prototype rows from the graphs whose maximum they won
     GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, s));
     GTG_TRY(proto_grad(dpooled, argmax, meta, B, n, d, w.pg, w.dT2c, s));
@@ -506,6 +522,7 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     g.B = W2; g.ldb = H; g.b_kc = false;
     g.C = w.dZ1c; g.ldc = H; g.M = rows; g.N = H; g.K = d; g.m_dev = all_rows;
     g.epi = EPI_MASK; g.aux = h1c; g.ldaux = H;
+    g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
     GTG_TRY(gemm(g, s));
     GTG_TRY(colsum_dev(w.dZ1c, rows, all_rows, H, H, w.cs, db1, s));
     // dW1[c][i] = sum over stored rows dZ1c[r][c] * adjc[r][i]   (prototype rows carry unit adjacency rows)
@@ -765,5 +782,33 @@ int gtg_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
 }
 
 size_t gtg_gemm_splitk_workspace_bytes(int M, int N, int K) { return gemm_splitk_workspace(M, N, K, 1); }
+
+// GEMM whose row count is read on the device (rows_dev, nullable), with the
+// tail split: C[:min(M,*rows_dev)] = op(A) * op(B).  Test / profiling hook
+// for the ragged encoder GEMMs.
+size_t gtg_gemm_rows_workspace_bytes(void)
+{
+    size_t tb, cb;
+    gemm_tail_workspace(&tb, &cb);
+    return tb + cb;
+}
+
+int gtg_gemm_f32_rows(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
+                      int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, const int32_t* rows_dev,
+                      void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_ACCUM, "unsupported epilogue");
+    size_t tb, cb;
+    gemm_tail_workspace(&tb, &cb);
+    GTG_REQUIRE(ws != nullptr && ws_bytes >= tb + cb, "workspace too small");
+    GemmDesc g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.a_kc = a_kc != 0; g.b_kc = b_kc != 0; g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux;
+    g.m_dev = rows_dev;
+    g.tail_ws = reinterpret_cast<float*>(ws);
+    g.tail_counters = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + tb);
+    GTG_TRY(clear_i32(g.tail_counters, (int64_t)(cb / sizeof(int32_t)), (hipStream_t)stream));
+    return gemm(g, (hipStream_t)stream);
+}
 
 }  // extern "C"

@@ -47,6 +47,9 @@ struct KArgs {
     const float* proto_val;  // pooled epilogue: value / row index to merge per (batch_dim[batch], col)
     const int32_t* proto_idx;
     int to_slabs;  // write raw partials to C viewed as [batch*splits][M][N]
+    float* tail_ws;         // tail split: accumulator slabs, one per (tail tile, part)
+    int32_t* tail_counters; // arrivals per tail tile
+    int tail_slots;         // resident block slots of the device for this kernel
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).
@@ -211,9 +214,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
     if (a.m_dev) {
         tiles_m = (Mr + BM - 1) / BM;
         live = tiles_m * a.tiles_n * a.splits;  // batch == 1 whenever m_dev is set
-        if ((int)blockIdx.x >= live) return;
     }
-    int bid = xcd_remap(blockIdx.x, live);
+    // Tail split: `live` tiles over `slots` resident blocks leave a last round of
+    // tail = live % slots tiles; cut each of those into `parts` K ranges so that
+    // the round fills the slots and takes 1/parts as long.
+    int parts = 1, part = 0, tail_tile = 0;
+    int bid;
+    if (KG == 1 && a.tail_ws != nullptr) {
+        live = tiles_m * a.tiles_n;  // batch 1, no split-K in this mode; the launch is padded by `slots` blocks
+        const int slots = a.tail_slots;
+        const int full = live / slots * slots, tail = live - full;
+        const int nk_all = (Kr + BK - 1) / BK;
+        int s = tail > 0 ? slots / tail : 1;
+        s = min(s, nk_all / 4);  // a part keeps at least four k steps
+        s = max(s, 1);
+        if ((int)blockIdx.x >= full + tail * s) return;
+        if ((int)blockIdx.x < full) {
+            bid = xcd_remap(blockIdx.x, full);
+        } else {
+            const int u = xcd_remap(blockIdx.x - full, tail * s);  // the parts of a tile share an XCD
+            tail_tile = u / s;
+            part = u % s;
+            parts = s;
+            bid = full + tail_tile;
+        }
+    } else {
+        if ((int)blockIdx.x >= live) return;
+        bid = xcd_remap(blockIdx.x, live);
+    }
     const int tn = bid % a.tiles_n;
     bid /= a.tiles_n;
     const int tm = bid % tiles_m;
@@ -234,6 +262,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
     if (a.k_dev && a.splits > 1) kps = ((Kr + a.splits - 1) / a.splits + BK - 1) / BK * BK;
     int k_begin = split * kps;
     int k_end = min(Kr, k_begin + kps);
+    if (parts > 1) {
+        const int per = (((Kr + BK - 1) / BK + parts - 1) / parts) * BK;
+        k_begin = part * per;
+        k_end = min(Kr, k_begin + per);
+    }
     // every wave group runs the same number of iterations (block-wide barriers); a group whose share is
     // empty or short multiplies zero tiles
     int nk = (k_end - k_begin + BK - 1) / BK;
@@ -348,6 +381,59 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
             }
         }
         return;
+    }
+
+    if (KG == 1 && parts > 1) {
+        // Leave this part's accumulators in its slab (register-major: every store instruction of a wave is
+        // one contiguous 256-byte run); the last part to arrive sums all of them, its own included, in part
+        // order, so the result does not depend on which block that is.  The slab words and the arrival
+        // counter are device-scope relaxed atomics (they go to the point of coherence between the XCDs' L2s
+        // without a whole-cache write-back); a block waits for its own stores to complete before it counts
+        // itself in, so whoever sees the full count can read every slab.
+        __shared__ int s_last;
+        float* slab0 = a.tail_ws + (long long)tail_tile * parts * (BM * BN);
+        float* mine = slab0 + (long long)part * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __hip_atomic_store(mine + ((i * TN + j) * 16 + e) * GT + tid, acc[i][j][e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) {
+            const int seen = __hip_atomic_fetch_add(&a.tail_counters[tail_tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (seen == parts - 1) ? 1 : 0;
+            if (seen == parts - 1)  // ready for the next launch
+                __hip_atomic_store(&a.tail_counters[tail_tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int p = 0; p < parts; ++p) {
+            const float* src = slab0 + (long long)p * (BM * BN) + tid;
+            f32x16 t[TM][TN];  // all loads of a part in flight before the first add
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        t[i][j][e] = __hip_atomic_load(src + ((i * TN + j) * 16 + e) * GT, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += t[i][j];
+        }
     }
 
     float* __restrict__ C;
@@ -514,7 +600,26 @@ int launch_cfg(const KArgs& k, bool akc, bool bkc, int grid, hipStream_t s)
     return check_launch("gemm_kernel");
 }
 
+// Resident 128x128-tile blocks of the device: two per CU (LDS bound).
+inline int tail_slots()
+{
+    static const int v = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int v2 = 2 * (cus > 0 ? cus : 256);
+        return v2 > 1024 ? 1024 : v2;  // the bound gemm_tail_workspace() sizes for
+    }();
+    return v;
+}
+
 }  // namespace
+
+void gemm_tail_workspace(size_t* ws_bytes, size_t* counter_bytes)
+{
+    const size_t slots = 1024;  // upper bound on tail_slots(): sized without touching the device
+    *ws_bytes = slots * 128 * 128 * sizeof(float);
+    *counter_bytes = slots * sizeof(int32_t);
+}
 
 int gemm_pick_splits(int M, int N, int K, int batch)
 {
@@ -609,7 +714,18 @@ int gemm(const GemmDesc& d, hipStream_t s)
         k.vecC = ((reinterpret_cast<uintptr_t>(d.C) & 15) == 0) && (d.ldc % 4 == 0) && (d.strideC % 4 == 0);
     k.vecAux = d.aux && ((reinterpret_cast<uintptr_t>(d.aux) & 15) == 0) && (d.ldaux % 4 == 0) && (d.strideAux % 4 == 0);
 
-    const long long grid = (long long)k.tiles_m * k.tiles_n * splits * d.batch;
+    k.tail_ws = nullptr;
+    k.tail_counters = nullptr;
+    k.tail_slots = 0;
+    long long grid = (long long)k.tiles_m * k.tiles_n * splits * d.batch;
+    static const bool tail_off = getenv("GTG_GEMM_TAIL") && atoi(getenv("GTG_GEMM_TAIL")) == 0;  // experiment hook
+    if (!tail_off && d.tail_ws != nullptr && d.tail_counters != nullptr && cfg == CFG_128 && d.batch == 1 && splits == 1 &&
+        d.epi != EPI_POOL) {
+        k.tail_ws = d.tail_ws;
+        k.tail_counters = d.tail_counters;
+        k.tail_slots = tail_slots();
+        grid += k.tail_slots;  // the split tail adds fewer than tail_slots blocks
+    }
     if (grid > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "gemm: grid too large");
 
     static const char* const kNames[CFG_COUNT][3] = {

@@ -68,6 +68,12 @@ __global__ __launch_bounds__(256) void adj_count_kernel(const int64_t* __restric
     atomicAdd(&counts[g * n * n + (t % n) * n + (s % n)], 1);
 }
 
+__global__ __launch_bounds__(256) void clear_i32_kernel(int32_t* __restrict__ p, int64_t count)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = 0;
+}
+
 // One wave per graph (n <= 64): deg_i = 1 + sum_j counts[i][j];
 // adj[i][j] = deg_i^-1/2 * (counts[i][j] + [i==j]) * deg_j^-1/2.
 __global__ __launch_bounds__(64) void adj_normalize_kernel(const int32_t* __restrict__ counts, int n,
@@ -529,6 +535,13 @@ int adj_count(const int64_t* ei, int64_t E, int64_t B, int n, int32_t* counts, i
     if (E == 0) return GTG_OK;
     hipLaunchKernelGGL(adj_count_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, ei, E, B, n, counts, err);
     return check_launch("adj_count_kernel");
+}
+
+int clear_i32(int32_t* p, int64_t count, hipStream_t s)
+{
+    if (count <= 0) return GTG_OK;
+    hipLaunchKernelGGL(clear_i32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, count);
+    return check_launch("clear_i32_kernel");
 }
 
 int adj_normalize(const int32_t* counts, int64_t B, int n, float* adj, hipStream_t s)

@@ -66,7 +66,18 @@ struct GemmDesc {
     // (bitwise reproducible; no float atomics).
     int splits = 1;
     float* slabs = nullptr;
+    // tail split (128x128 tiles, batch 1, no split-K): the tiles of the last, partly
+    // filled round of resident blocks are each cut along K into as many parts as
+    // fill the idle block slots; the parts leave their accumulators in `tail_ws`
+    // and the last one to arrive (counted in `tail_counters`) sums them in part
+    // order and runs the epilogue.  tail_counters must be zero on entry and is
+    // zero again on exit.  Sizes: gemm_tail_workspace().
+    float* tail_ws = nullptr;
+    int32_t* tail_counters = nullptr;
 };
+
+// Tail-split workspace: *ws_bytes of float slabs and *counter_bytes of int32 counters.
+void gemm_tail_workspace(size_t* ws_bytes, size_t* counter_bytes);
 
 // Bytes of slab workspace gemm() needs for this shape (0 when it will not split).
 size_t gemm_splitk_workspace(int M, int N, int K, int batch);
@@ -75,6 +86,7 @@ int gemm(const GemmDesc& d, hipStream_t s);
 
 // ---- element-wise / reduction kernels (graph_ops.hip) -----------------------
 int adj_count(const int64_t* edge_index, int64_t E, int64_t B, int n, int32_t* counts, int32_t* err, hipStream_t s);
+int clear_i32(int32_t* p, int64_t count, hipStream_t s);  // a kernel, not a memset: replays correctly in HIP graphs
 int adj_normalize(const int32_t* counts, int64_t B, int n, float* adj, hipStream_t s);
 int pool_bwd_gather(const float* adj, const float* dpool, const int32_t* argmax, int64_t B, int n, int d,
                     float* dT2, hipStream_t s);

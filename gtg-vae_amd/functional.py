@@ -296,3 +296,19 @@ def gemm(A, B, a_kc=True, b_kc=True, bias=None, epilogue=0, aux=None, out=None, 
                          ptr(_f32c(bias)), epilogue, ptr(_f32c(aux)), aux.stride(0) if aux is not None else 0,
                          ptr(slabs), nb, stream_ptr()), "gtg_gemm_f32")
     return C
+
+
+def gemm_rows(A, B, a_kc=True, b_kc=True, rows_dev=None, bias=None, epilogue=0, aux=None, out=None):
+    """Test/profiling hook over gtg_gemm_f32_rows: the GEMM of the compact-row
+    encoder (row count read on the device, tail tiles split along K)."""
+    L = _lib.lib()
+    A, B = _f32c(A), _f32c(B)
+    M, K = (A.shape[0], A.shape[1]) if a_kc else (A.shape[1], A.shape[0])
+    N = B.shape[0] if b_kc else B.shape[1]
+    C = out if out is not None else torch.zeros((M, N), dtype=torch.float32, device=A.device)
+    ws = _ws(L.gtg_gemm_rows_workspace_bytes(), A.device)
+    check(L.gtg_gemm_f32_rows(ptr(A), ptr(B), ptr(C), M, N, K, A.stride(0), B.stride(0), C.stride(0), int(a_kc),
+                              int(b_kc), ptr(_f32c(bias)), epilogue, ptr(_f32c(aux)),
+                              aux.stride(0) if aux is not None else 0, ptr(rows_dev), ptr(ws), ws.numel(), stream_ptr()),
+          "gtg_gemm_f32_rows")
+    return C

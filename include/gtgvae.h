@@ -183,6 +183,17 @@ int gtg_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
                  size_t slab_bytes, void* stream);
 size_t gtg_gemm_splitk_workspace_bytes(int M, int N, int K);
 
+/* The same GEMM with the row count read on the device: only the first
+ * min(M, *rows_dev) rows of C are computed and written (rows_dev may be NULL).
+ * When the tiles do not fill a whole number of rounds of resident blocks, the
+ * last round's tiles are cut along K and summed in a fixed order (bitwise
+ * reproducible).  This is what the compact-row encoder GEMMs run; exported for
+ * tests and profiling.  ws: gtg_gemm_rows_workspace_bytes() device bytes. */
+size_t gtg_gemm_rows_workspace_bytes(void);
+int gtg_gemm_f32_rows(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
+                      int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, const int32_t* rows_dev,
+                      void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,3 +82,53 @@ def test_split_k_is_deterministic_and_correct():
     assert (got.double() - want).abs().max().item() < 2e-3
     nosplit = Fn.gemm(A, B, False, False, split_k=False)
     assert (nosplit.double() - want).abs().max().item() < 5e-2  # one sequential fp32 chain over K=32768
+
+
+# 128x128 tiles over 512 resident block slots: (rows, N) picked so that the last round is empty, nearly
+# empty (many parts per tile), half full and nearly full (no split), with row counts known to the host
+# and read from the device
+@pytest.mark.parametrize("M,rows,N,K", [
+    (20800, 20763, 512, 1024),   # 652 tiles: 140 in the tail, three parts each
+    (20800, None, 512, 1024),
+    (16384, 16384, 512, 256),    # exactly one round
+    (16500, 16500, 512, 1024),   # 4 tail tiles (capped by the k steps per part)
+    (33000, 24000, 1024, 512),   # tail above half the slots: no split
+    (33000, 129, 1024, 512),     # a single round, partly filled
+    (700, 1, 256, 2048),
+])
+@pytest.mark.parametrize("layout", ["NT", "NN"])
+def test_rows_on_device_with_tail_split(M, rows, N, K, layout):
+    from gtg_vae_amd import functional as Fn
+
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda") if layout == "NT" else torch.randn(K, N, device="cuda")
+    bias = torch.randn(N, device="cuda")
+    rows_dev = None if rows is None else torch.tensor([rows], dtype=torch.int32, device="cuda")
+    live = M if rows is None else rows
+    out = torch.full((M, N), 7.0, device="cuda")
+    got = Fn.gemm_rows(A, B, True, layout == "NT", rows_dev=rows_dev, bias=bias, epilogue=1, out=out).clone()
+    again = Fn.gemm_rows(A, B, True, layout == "NT", rows_dev=rows_dev, bias=bias, epilogue=1, out=out)
+    assert torch.equal(got, again)                       # fixed summation order: bitwise reproducible
+    assert bool((got[live:] == 7.0).all())               # rows past the device count are not written
+    want = torch.relu(A[:live].double() @ (B.double().t() if layout == "NT" else B.double()) + bias.double())
+    err = (got[:live].double() - want).abs().max().item()
+    assert err < _tol(K) * 40, err
+    # the plain kernel (no tail split) on the same rows
+    plain = Fn.gemm(A[:live], B, True, layout == "NT", bias=bias, epilogue=1)
+    assert (plain - got[:live]).abs().max().item() < _tol(K) * 40
+
+
+def test_rows_on_device_mask_epilogue():
+    from gtg_vae_amd import functional as Fn
+
+    torch.manual_seed(3)
+    M, rows, N, K = 20800, 20500, 1024, 512
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(K, N, device="cuda")
+    aux = torch.randn(M, N, device="cuda")
+    rows_dev = torch.tensor([rows], dtype=torch.int32, device="cuda")
+    got = Fn.gemm_rows(A, B, True, False, rows_dev=rows_dev, epilogue=3, aux=aux)
+    want = torch.where(aux[:rows] > 0, A[:rows].double() @ B.double(), torch.zeros((), dtype=torch.float64, device="cuda"))
+    assert (got[:rows].double() - want).abs().max().item() < _tol(K) * 40
+    assert bool((got[rows:] == 0).all())
