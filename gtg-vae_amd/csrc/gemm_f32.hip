@@ -628,7 +628,8 @@ int gemm_pick_splits(int M, int N, int K, int batch)
     cfg_dims(pick_cfg(M, N, K, batch, EPI_STORE), bm, bn);
     const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     if (tiles >= 256 || K < 1024) return 1;
-    long long want = (768 + tiles - 1) / tiles;
+    // one full round of resident blocks (two per CU on the 256 CUs for every configuration that gets here)
+    long long want = 512 / tiles;
     const long long maxs = K / 256;
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
