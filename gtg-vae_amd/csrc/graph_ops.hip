@@ -328,17 +328,6 @@ __global__ __launch_bounds__(256) void adj_compact_kernel(const float* __restric
     for (int idx = threadIdx.x; idx < nb * n; idx += 256) dst[idx] = src[idx];
 }
 
-// P1[i][c] = relu(W1[c][i] + b1[c])  (first-layer row of an untouched node i)
-__global__ __launch_bounds__(256) void proto_h1_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int n,
-                                                       int H, const int32_t* __restrict__ row_base,
-                                                       float* __restrict__ h1c)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * H) return;
-    const int i = idx / H, c = idx - i * H;
-    h1c[(int64_t)row_base[0] * H + idx] = fmaxf(W1[(int64_t)c * n + i] + b1[c], 0.f);
-}
-
 // S[k][c] = max_{i >= k} Q[i][c] with its row index (lowest index on ties); S[n] = none
 __global__ __launch_bounds__(256) void proto_suffix_max_kernel(const float* __restrict__ t2c,
                                                                const int32_t* __restrict__ row_base,
@@ -654,12 +643,6 @@ int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_
     if (rc || adjc == nullptr) return rc;
     hipLaunchKernelGGL(adj_compact_kernel, dim3((unsigned)B + 1), dim3(256), 0, s, adj, meta, B, n, adjc);
     return check_launch("adj_compact_kernel");
-}
-
-int proto_h1(const float* W1, const float* b1, int n, int H, const int32_t* row_base, float* h1c, hipStream_t s)
-{
-    hipLaunchKernelGGL(proto_h1_kernel, dim3((n * H + 255) / 256), dim3(256), 0, s, W1, b1, n, H, row_base, h1c);
-    return check_launch("proto_h1_kernel");
 }
 
 int proto_suffix_max(const float* t2c, const int32_t* row_base, const float* b2, int n, int d, float* sval,

@@ -98,7 +98,6 @@ int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int 
 // compact node rows (identity features): meta = [n_b (B) | row offsets (B+1) | R + n], adjc = compact adjacency
 // rows followed by n identity rows (the prototype rows)
 int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, hipStream_t s);
-int proto_h1(const float* W1, const float* b1, int n, int H, const int32_t* row_base, float* h1c, hipStream_t s);
 int proto_suffix_max(const float* t2c, const int32_t* row_base, const float* b2, int n, int d, float* sval,
                      int32_t* sidx, hipStream_t s);
 int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,
