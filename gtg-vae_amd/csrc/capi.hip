@@ -429,16 +429,16 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float
     GTG_TRY(clear_i32(w.tail_cnt, (int64_t)w.tail_cnt_count, s));
     GTG_TRY(graph_meta(counts, adj, B, n, meta, adjc, s));
     GemmDesc g;
-    // H1c[off_b + i] = relu(A_b[:n_b,:n_b] * W1^T[:n_b] + b1)
-    g.A = adj; g.lda = n; g.a_kc = true; g.strideA = (long long)n * n;
-    g.B = W1; g.ldb = n; g.b_kc = true; g.strideB = 0;
-    g.C = h1c; g.ldc = H; g.off_c = true;
-    g.M = n; g.N = H; g.K = n; g.batch = B;
-    g.batch_dim = n_real; g.batch_off = row_off;
+    // H1c = relu(adjc * W1^T + b1) over the R + n stored rows: a graph's compact adjacency rows are zero past
+    // its n_b columns, so one plain GEMM with K = n serves every graph, and the unit rows appended to adjc
+    // give the prototype rows relu(W1^T + b1) in the same launch
+    g.A = adjc; g.lda = n; g.a_kc = true;
+    g.B = W1; g.ldb = n; g.b_kc = true;
+    g.C = h1c; g.ldc = H;
+    g.M = rows; g.N = H; g.K = n; g.m_dev = all_rows;
     g.bias = b1; g.epi = EPI_RELU;
+    g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
     GTG_TRY(gemm(g, s));
-    // prototype rows R .. R+n-1: relu(W1^T + b1)
-    GTG_TRY(proto_h1(W1, b1, n, H, real_rows, h1c, s));
     // T2c = H1c * W2^T over the R + n stored rows
     g = GemmDesc();
     g.A = h1c; g.lda = H; g.B = W2; g.ldb = H; g.C = w.t2c; g.ldc = d;
