@@ -559,11 +559,12 @@ int gtg_latent_fwd(const float* h, const float* Wmu, const float* bmu, const flo
     Carver c(ws, ws_bytes);
     float* partial = c.take<float>((size_t)((num_graphs * d + 255) / 256) + 1);
     if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_latent_fwd: workspace too small");
+    // both linears in one launch: a batch of two over the same input, the second operand set addressed by its
+    // element distance from the first
     GemmDesc g;
     g.A = h; g.lda = d; g.B = Wmu; g.ldb = d; g.C = mu; g.ldc = d;
     g.M = B; g.N = d; g.K = d; g.bias = bmu;
-    GTG_TRY(gemm(g, s));
-    g.B = Wlv; g.C = logvar; g.bias = blv;
+    g.batch = 2; g.strideA = 0; g.strideB = Wlv - Wmu; g.strideC = logvar - mu; g.strideBias = blv - bmu;
     GTG_TRY(gemm(g, s));
     return reparam_kl(mu, logvar, eps, B, d, z, partial, kl, s);
 }
@@ -592,10 +593,16 @@ int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const flo
     g.A = dmu; g.lda = d; g.a_kc = false;
     g.B = h; g.ldb = d; g.b_kc = false;
     g.C = dWmu; g.ldc = d; g.M = d; g.N = d; g.K = B;
-    g.splits = splits; g.slabs = slabs;
-    GTG_TRY(gemm(g, s));
-    g.A = dlv; g.C = dWlv;
-    GTG_TRY(gemm(g, s));
+    if (splits > 1) {
+        g.splits = splits; g.slabs = slabs;
+        GTG_TRY(gemm(g, s));
+        g.A = dlv; g.C = dWlv;
+        GTG_TRY(gemm(g, s));
+    } else {
+        // both weight gradients in one launch (dmu and dlv are adjacent in the workspace)
+        g.batch = 2; g.strideA = dlv - dmu; g.strideB = 0; g.strideC = dWlv - dWmu;
+        GTG_TRY(gemm(g, s));
+    }
     GTG_TRY(colsum(dmu, B, d, d, cs, dbmu, s));
     GTG_TRY(colsum(dlv, B, d, d, cs, dblv, s));
     // dh = dmu * Wmu + dlogvar * Wlv

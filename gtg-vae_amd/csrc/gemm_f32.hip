@@ -33,7 +33,7 @@ struct KArgs {
     const float* aux;
     float* pool_val;
     int32_t* pool_idx;
-    long long strideA, strideB, strideC, strideAux;
+    long long strideA, strideB, strideC, strideAux, strideBias;
     int M, N, K;
     int lda, ldb, ldc, ldaux;
     int tiles_m, tiles_n, splits, k_per_split;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
     }
     const float* __restrict__ aux = a.aux ? a.aux + batch * a.strideAux + (a.off_c ? row_off * a.ldaux : 0) : nullptr;
     const int epi = a.to_slabs ? (int)EPI_STORE : a.epi;
-    const float* __restrict__ bias = a.to_slabs ? nullptr : a.bias;
+    const float* __restrict__ bias = (a.to_slabs || a.bias == nullptr) ? nullptr : a.bias + batch * a.strideBias;
 
     // Stage the wave's WTM x WTN accumulator tile through LDS (the operand
     // buffers are free after the last barrier of the main loop) so that global
@@ -673,6 +673,7 @@ int gemm(const GemmDesc& d, hipStream_t s)
     k.strideB = d.strideB;
     k.strideC = d.strideC;
     k.strideAux = d.strideAux;
+    k.strideBias = d.strideBias;
     k.M = d.M;
     k.N = d.N;
     k.K = d.K;

@@ -362,15 +362,23 @@ __global__ __launch_bounds__(256) void pool_bwd_gather_compact_kernel(const floa
                                                                       const int32_t* __restrict__ meta, int64_t B,
                                                                       int n, int d, float* __restrict__ dT2)
 {
+    // the graph's adjacency block sits in LDS, one padded row per winning-row lookup
+    __shared__ float sadj[64 * 65];
     const int64_t b = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d) return;
     const int nb = meta[b], off = meta[B + b];
+    const float* src = adj + b * n * n;
+    for (int idx = threadIdx.x; idx < nb * n; idx += 256) sadj[(idx / n) * 65 + (idx % n)] = src[idx];
+    __syncthreads();
+    if (c >= d) return;
     const float g = dpool[b * d + c];
     const int am = argmax[b * d + c];
-    const float* arow = adj + b * n * n + (int64_t)am * n;
+    // a prototype row that won the maximum has no edge to a stored row
+    const float scale = (am < nb) ? g : 0.f;
+    const float* arow = sadj + (am < nb ? am : 0) * 65;
     float* out = dT2 + (int64_t)off * d + c;
-    for (int j = 0; j < nb; ++j) out[(int64_t)j * d] = (am < nb) ? arow[j] * g : 0.f;
+#pragma unroll 4
+    for (int j = 0; j < nb; ++j) out[(int64_t)j * d] = arow[j] * scale;
 }
 
 // gradient reaching the prototype rows: dQ[i][c] = sum over graphs whose pooled
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(256) void pool_bwd_gather_compact_kernel(const floa
 // of the batch) walks its graphs in order, each thread adding into its own
 // column of an LDS (n x 64) table; stage 2 adds the segments in order and
 // writes the rows at offset R of dT2c.  Ordered: reproducible.
-constexpr int PG_SEG = 8;
+constexpr int PG_SEG = 32;
 __global__ __launch_bounds__(64) void proto_grad_stage1(const float* __restrict__ dpool,
                                                         const int32_t* __restrict__ argmax,
                                                         const int32_t* __restrict__ meta, int64_t B, int n, int d,
@@ -392,9 +400,20 @@ __global__ __launch_bounds__(64) void proto_grad_stage1(const float* __restrict_
     const int64_t per = (B + PG_SEG - 1) / PG_SEG;
     const int64_t b0 = seg * per, b1 = min(B, b0 + per);
     if (c < d) {
-        for (int64_t b = b0; b < b1; ++b) {
-            const int am = argmax[b * d + c];
-            if (am >= meta[b]) tab[am * 64 + tc] += dpool[b * d + c];
+        // loads of eight graphs in flight, then the ordered adds into this thread's own LDS column
+        for (int64_t b = b0; b < b1; b += 8) {
+            int am[8], nb[8];
+            float g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t bb = min(b + u, b1 - 1);
+                am[u] = argmax[bb * d + c];
+                nb[u] = meta[bb];
+                g[u] = dpool[bb * d + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b + u < b1 && am[u] >= nb[u]) tab[am[u] * 64 + tc] += g[u];
         }
         for (int i = 0; i < n; ++i) partial[((int64_t)seg * n + i) * d + c] = tab[i * 64 + tc];
     }

@@ -45,7 +45,7 @@ struct GemmDesc {
     int lda = 0, ldb = 0, ldc = 0;
     bool a_kc = true, b_kc = true;
     int batch = 1;
-    long long strideA = 0, strideB = 0, strideC = 0;
+    long long strideA = 0, strideB = 0, strideC = 0, strideBias = 0;  // element offsets per batch (may be negative)
     int epi = EPI_STORE;
     const float* bias = nullptr;
     const float* aux = nullptr;
