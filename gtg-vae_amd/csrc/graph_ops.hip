@@ -125,15 +125,17 @@ __global__ __launch_bounds__(256) void pool_bwd_gather_kernel(const float* __res
 // partial[chunk][col] and a second launch adds the chunks in order.
 // ---------------------------------------------------------------------------
 constexpr int CS_COLS = 64;
-constexpr int CS_RL = 16;
 __host__ __device__ inline int cs_chunk_rows(int64_t rows)
 {
     return rows <= 1024 ? (int)(rows > 0 ? rows : 1) : 512;
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t rows, int cols, int ld,
-                                                     int chunk, int vec, const int* __restrict__ rows_dev,
-                                                     float* __restrict__ dst)
+// CS_RL row lanes: 16 (256 threads) for the chunks of a tall matrix, 64 (1024 threads) when the whole matrix is
+// one short chunk and the few blocks of the launch need every load in flight at once
+template <int CS_RL>
+__global__ __launch_bounds__(16 * CS_RL) void colsum_kernel(const float* __restrict__ X, int64_t rows, int cols, int ld,
+                                                            int chunk, int vec, const int* __restrict__ rows_dev,
+                                                            float* __restrict__ dst)
 {
     __shared__ f32x4 sm[CS_RL][CS_COLS / 4];
     if (rows_dev) rows = min(rows, (int64_t)rows_dev[0]);
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (col < cols) {
         if (vec && col + 3 < cols) {
+#pragma unroll 8
             for (int64_t r = r0 + rl; r < r1; r += CS_RL) s += *reinterpret_cast<const f32x4*>(X + r * ld + col);
         } else {
             for (int64_t r = r0 + rl; r < r1; r += CS_RL)
@@ -589,15 +592,18 @@ int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int 
     const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ld % 4 == 0);
     const dim3 grid((cols + CS_COLS - 1) / CS_COLS, nchunks > 0 ? nchunks : 1);
     if (nchunks <= 1) {
-        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, rows_dev, out);
+        if (rows > 64)
+            hipLaunchKernelGGL(colsum_kernel<64>, grid, dim3(1024), 0, s, X, rows, cols, ld, chunk, vec, rows_dev, out);
+        else
+            hipLaunchKernelGGL(colsum_kernel<16>, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, rows_dev, out);
         return check_launch("colsum_kernel");
     }
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, rows_dev, partial);
+    hipLaunchKernelGGL(colsum_kernel<16>, grid, dim3(256), 0, s, X, rows, cols, ld, chunk, vec, rows_dev, partial);
     int rc = check_launch("colsum_kernel");
     if (rc) return rc;
     // second stage: the partials form an (nchunks x cols) matrix; same kernel, one chunk
     const int vec2 = ((reinterpret_cast<uintptr_t>(partial) & 15) == 0) && (cols % 4 == 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + CS_COLS - 1) / CS_COLS, 1), dim3(256), 0, s, partial,
+    hipLaunchKernelGGL(colsum_kernel<16>, dim3((cols + CS_COLS - 1) / CS_COLS, 1), dim3(256), 0, s, partial,
                        (int64_t)nchunks, cols, cols, nchunks, vec2, (const int*)nullptr, out);
     return check_launch("colsum_kernel");
 }

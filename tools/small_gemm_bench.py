@@ -20,6 +20,12 @@ shapes = [  # (name, A shape, B shape, a_kc, b_kc)
     ("tn 512x512x512", (512, 512), (512, 512), False, False),
     ("tn 2080x512x512", (512, 2080), (512, 512), False, False),
     ("tn 1024x64x20800", (20800, 1024), (20800, 64), False, False),
+    ("nt 512x2048x512", (512, 512), (2048, 512), True, True),
+    ("nt 512x2112x512", (512, 512), (2112, 512), True, True),
+    ("nt 512x1024x512", (512, 512), (1024, 512), True, True),
+    ("nt 512x4096x512", (512, 512), (4096, 512), True, True),
+    ("tn 2048x512x512", (512, 2048), (512, 512), False, False),
+    ("nn 512x512x2048", (512, 2048), (2048, 512), True, False),
 ]
 for name, sa, sb, akc, bkc in shapes:
     A = torch.randn(sa, device=dev)
