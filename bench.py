@@ -10,10 +10,13 @@ are resident in HBM before the timed region.  Workload = BASELINE.json
 configs[2]: N=64 nodes, batch 512 PER GPU (weak scaling), d=512, mlp_hid=512,
 fp32.  For N>1 launch with torch.distributed.run (one rank per GPU, RCCL).
 
+The timed region replays the step as HIP graphs (--eager: plain launches).
 Prints ONE JSON line (rank 0) with the headline metric, the roofline of the
-dominant kernel (fp32 MFMA GEMM, timed with HIP events inside the timed
-region) and, at N=1, the CPU baseline (the build-owned PyTorch-CPU oracle of
-the same step, timed on this host's cores) plus the batched-MST read-out figure.
+dominant kernel (fp32 MFMA GEMM; executed FLOPs over its HIP-event time, taken
+in the timed region with --eager, else over --profile-steps eager steps that
+continue the same loop right after it) and, at N=1, the CPU baseline (the
+build-owned PyTorch-CPU oracle of the same step, timed on this host's cores)
+plus the batched-MST read-out figure.
 """
 import argparse
 import json

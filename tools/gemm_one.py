@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Launch one GEMM shape a few times (for rocprofv3 --pmc passes).
-usage: gemm_one.py {nt|nn|nnmask|tn} [reps]"""
+usage: gemm_one.py {nt|nn|nnmask|tn|rows_nnmask|rows_nt} [reps]
+The rows_* shapes are the compact-row encoder GEMMs: 32832 allocated rows of which the
+device-side count (20759, the mean of the benchmark's batches) are computed."""
 import os
 import sys
 
@@ -20,8 +22,25 @@ elif which == "nn":
 elif which == "nnmask":
     A, B, akc, bkc, epi = torch.randn(BN, D, device="cuda"), torch.randn(D, H, device="cuda"), True, False, 3
     aux = torch.randn(BN, H, device="cuda")
+elif which.startswith("rows_"):
+    pass
 else:
     A, B, akc, bkc, epi, aux = torch.randn(BN, D, device="cuda"), torch.randn(BN, H, device="cuda"), False, False, 0, None
+ROWS = 20759
+if which.startswith("rows_"):
+    M = 32832
+    rd = torch.tensor([ROWS], dtype=torch.int32, device="cuda")
+    if which == "rows_nnmask":
+        A, B, akc, bkc, epi = torch.randn(M, D, device="cuda"), torch.randn(D, H, device="cuda"), True, False, 3
+        aux = torch.randn(M, H, device="cuda")
+    else:
+        A, B, akc, bkc, epi, aux = torch.randn(M, H, device="cuda"), torch.randn(D, H, device="cuda"), True, True, 0, None
+    out = torch.empty((M, B.shape[0] if bkc else B.shape[1]), device="cuda")
+    for _ in range(reps):
+        Fn.gemm_rows(A, B, akc, bkc, rows_dev=rd, epilogue=epi, aux=aux, out=out)
+    torch.cuda.synchronize()
+    print("done", which, out.shape)
+    sys.exit(0)
 for _ in range(reps):
     out = Fn.gemm(A, B, akc, bkc, epilogue=epi, aux=aux)
 torch.cuda.synchronize()
