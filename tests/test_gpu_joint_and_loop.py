@@ -1,0 +1,130 @@
+"""GPU tests of the layers around the graph hot path: the joint text+graph
+forward (gtvae.py:95-126), the named benchmark configurations A and B as
+whole training steps, and the train()/dev() loop."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+
+def _relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def _tokens(B, T, vocab, seed):
+    from make_text_golden import make_tokens
+
+    return torch.from_numpy(make_tokens(T, B, vocab, 0, seed)).t().contiguous()  # (B, T) as train.py feeds dec_seq
+
+
+def test_joint_forward_matches_composition_of_reference_pieces():
+    """text=True: joint_h = (text_h + graph_h)/2, loss = kl_w*KL + text_recon, graph_recon only reported
+    (gtvae.py:107-124).  The graph pieces come from the CPU oracle, the text pieces from the same DAE
+    weights run on the CPU (the DAE is pinned to the reference's outputs in test_text_branch.py)."""
+    from gtg_vae_amd import GTVAE
+    from gtg_vae_amd.data import synth_graph_batch
+    from gtg_vae_amd.text_vae import DAE
+    from make_text_golden import fill_parameters
+    from oracle import graphvae_oracle as O
+
+    B, N, d, hid, vocab, T = 6, 10, 32, 64, 60, 9
+    torch.manual_seed(0)
+    model = GTVAE(N, d, hid, N, vocab, 0, text=True)
+    fill_parameters(model.text_vae, scale=0.05)
+    model.eval()  # no dropout / word noise: deterministic
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = synth_graph_batch(B, N, seed=5)
+    dec_seq = _tokens(B, T, vocab, 3)
+    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(2))
+    kl_w = 0.4
+
+    # ---- composition on the CPU
+    gp = {k.replace("graph_vae.", ""): v for k, v in sd.items() if not k.startswith("text_vae.")}
+    graph_h = O.encode(gp, None, batch.edge_index, B, N)
+    dae = DAE(d, vocab, 0)
+    dae.load_state_dict({k[len("text_vae."):]: v for k, v in sd.items() if k.startswith("text_vae.")})
+    dae.eval()
+    inputs = dec_seq.t()
+    targets = torch.cat((dec_seq[:, 1:], torch.zeros(B, 1, dtype=dec_seq.dtype)), 1).long().t()
+    with torch.no_grad():
+        text_h = dae.autoenc(inputs, targets)
+        joint_h = (text_h + graph_h) / 2
+        z, mu, logvar, kl = O.latent(gp, joint_h, eps)
+        logits, _ = dae.decode(z, inputs)
+        text_rec = dae.loss_rec(logits, targets).mean()
+        text_acc = dae.accuracy(logits, targets)
+        out = O.decode(gp, z)
+        graph_rec = O.recon_loss(out, batch.adj_padded)
+    want_loss = kl_w * kl + text_rec
+
+    # ---- the module on the GPU
+    model = model.cuda()
+    gb = batch.to("cuda")
+    with torch.no_grad():
+        res = model(gb.dense_x(), gb.edge_index, gb.batch, gb.adj_padded, gb.gold_edges, dec_seq.cuda(), kl_w,
+                    eps=eps.cuda())
+    assert len(res) == 10 and res[7:] == (0, 0, 0)
+    loss, acc, gkl, grec, trec = res[0], res[1], res[2], res[3], res[4]
+    assert abs(gkl.item() - kl.item()) <= 2e-5 * abs(kl.item())
+    assert abs(trec.item() - text_rec.item()) <= 2e-5 * abs(text_rec.item())
+    assert abs(grec.item() - graph_rec.item()) <= 2e-5 * abs(graph_rec.item())
+    assert abs(loss.item() - want_loss.item()) <= 2e-5 * abs(want_loss.item())
+    assert abs(acc - text_acc) < 1e-6
+
+
+@pytest.mark.parametrize("name,B,N,d,hid", [("A", 64, 10, 32, 512), ("B", 256, 32, 256, 512)])
+def test_named_config_training_step_matches_oracle(name, B, N, d, hid):
+    """Reference defaults (A) and the mid-size configuration (B): losses, every gradient and the
+    parameters after one Adam step, against the oracle on the same weights, batch and eps."""
+    from gtg_vae_amd.data import synth_graph_batch
+    from gtg_vae_amd.trainer import GraphVAETrainer
+    from oracle import graphvae_oracle as O
+
+    params = O.init_params(N, d, hid, N, seed=0)
+    tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    batch = synth_graph_batch(B, N, seed=1234)
+    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(9))
+    loss, rec, kl, _ = O.graph_step_loss(p, None, batch.edge_index, batch.adj_padded, eps, 0.5, B, N)
+    loss.backward()
+    for use_graph in (False, True):
+        tr.load_state_dict(params)
+        res = tr.step(batch.to("cuda"), eps.cuda(), kl_w=0.5, update=False, use_graph=use_graph)
+        assert tr.edges_ok()
+        assert abs(res["recon"].item() - rec.item()) <= 1e-5 * abs(rec.item())
+        assert abs(res["kl"].item() - kl.item()) <= 1e-5 * abs(kl.item()) + 1e-7
+        for k in p:
+            assert _relerr(tr.named_grads()[k], p[k].grad) < 1e-4, (name, use_graph, k)
+
+
+def test_train_and_dev_loop_runs_and_learns(capsys):
+    """train.py:284-355 / 228-282 mirrored: per-epoch KL weight min(epoch/500, 1), batch-size-weighted epoch
+    means, dev pass with the batched spanning-tree read-out; the printed field names are the reference's."""
+    from gtg_vae_amd.data import DataLoader, synth_graph_list
+    from gtg_vae_amd.train import dev, train
+    from gtg_vae_amd.trainer import GraphVAETrainer
+
+    N, d, hid = 10, 32, 64
+    data = synth_graph_list(300, N, seed=1)
+    trn, dv = DataLoader(data[:256], batch_size=64, nmax=N), DataLoader(data[256:], batch_size=64, nmax=N)
+    tr = GraphVAETrainer(N, d, hid, N, device="cuda", seed=0, lr=1e-2)
+    gen = torch.Generator().manual_seed(0)
+    hist = train(trn, dv, tr, epochs=6, generator=gen)
+    printed = capsys.readouterr().out
+    for field in ("Epoch loss:", "Epoch graph_recon loss:", "Epoch joint_kl_loss:", "kl_anneal_w:", "DEV",
+                  "Epoch edge_recall:", "Epoch edge_precision:"):
+        assert field in printed
+    assert hist[0]["kl"] >= 0 and all(np.isfinite(h["loss"]) for h in hist)
+    assert hist[-1]["graph_recon"] < 0.8 * hist[0]["graph_recon"]       # it learns
+    last = hist[-1]["dev"]
+    assert 0.0 <= last["edge_recall"] <= 1.0 and 0.0 <= last["edge_precision"] <= 1.0
+    # ragged tail: 300 - 256 = 44 dev graphs in one short batch
+    again = dev(dv, tr, 0, 0.0, gen, quiet=True)
+    assert np.isfinite(again["loss"])
