@@ -545,17 +545,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 enum TileCfg { CFG_128, CFG_64x128, CFG_64, CFG_64_K2, CFG_32_K4, CFG_COUNT };
 
-// Experiment hook: GTG_GEMM_SMALL=0..2 forces the configuration used for GEMMs with few tiles
-// (0 = 64x64, 1 = 64x64 with two K groups, 2 = 32x32 with four K groups).
-inline int small_override()
-{
-    static const int v = [] {
-        const char* e = getenv("GTG_GEMM_SMALL");
-        return e ? atoi(e) : -1;
-    }();
-    return v;
-}
-
 inline TileCfg pick_cfg(int M, int N, int K, int batch, int epi)
 {
     if (epi == EPI_POOL) return CFG_64x128;
@@ -565,11 +554,6 @@ inline TileCfg pick_cfg(int M, int N, int K, int batch, int epi)
     // short-and-wide weight-gradient shapes: the big tile still fills the chip once K is split
     if (batch == 1 && M >= 128 && N >= 128 && t128 * (K / 1024) >= 192) return CFG_128;
     const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64) * batch;
-    const int ov = small_override();
-    if (ov == 0) return CFG_64;
-    if (ov == 1) return K >= 128 ? CFG_64_K2 : CFG_64;
-    if (ov == 2) return (K >= 256 && t64 <= 256) ? CFG_32_K4 : (K >= 128 ? CFG_64_K2 : CFG_64);
-    if (ov == 3) return K >= 256 ? CFG_32_K4 : CFG_64;
     // few tiles: 32x32 tiles put one on every CU and four wave groups quarter the dependent K chain
     if (K >= 256 && t64 <= 256) return CFG_32_K4;
     return K >= 128 ? CFG_64_K2 : CFG_64;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the batch-sized GEMM shapes of the latent head and the decoder
 (M = batch) with HIP events; the tile configuration is chosen by the library
-(GTG_GEMM_SMALL overrides it for experiments)."""
+(the library picks the tile configuration)."""
 import os
 import sys
 
