@@ -128,3 +128,37 @@ def test_train_and_dev_loop_runs_and_learns(capsys):
     # ragged tail: 300 - 256 = 44 dev graphs in one short batch
     again = dev(dv, tr, 0, 0.0, gen, quiet=True)
     assert np.isfinite(again["loss"])
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_random_awkward_shapes_match_oracle(case):
+    """Odd sizes end to end (N from 1 to 64, single-graph batches, d or hid of 1, non-multiples of every
+    tile size): losses and all gradients of the fused step against the oracle, eager and graph replay."""
+    from gtg_vae_amd.data import synth_graph_batch
+    from gtg_vae_amd.trainer import GraphVAETrainer
+    from oracle import graphvae_oracle as O
+
+    rng = np.random.default_rng(1000 + case)
+    N = int(rng.choice([1, 2, 3, 5, 10, 17, 31, 33, 48, 63, 64]))
+    B = int(rng.choice([1, 2, 3, 7, 33, 130, 257]))
+    d = int(rng.choice([1, 2, 3, 12, 30, 64, 100]))
+    hid = int(rng.choice([1, 5, 64, 96, 130]))
+    params = O.init_params(N, d, hid, N, seed=case)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = 0.1 * torch.randn(params[k].shape, generator=torch.Generator().manual_seed(case))
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    batch = synth_graph_batch(B, N, seed=100 + case)
+    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(case))
+    kl_w = float(rng.uniform(0, 1))
+    loss, rec, kl, _ = O.graph_step_loss(p, None, batch.edge_index, batch.adj_padded, eps, kl_w, B, N)
+    loss.backward()
+    tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params)
+    for use_graph in (False, True):
+        res = tr.step(batch.to("cuda"), eps.cuda(), kl_w=kl_w, update=False, use_graph=use_graph)
+        assert tr.edges_ok()
+        assert abs(res["recon"].item() - rec.item()) <= 1e-5 * abs(rec.item())
+        assert abs(res["kl"].item() - kl.item()) <= 1e-5 * abs(kl.item()) + 1e-7
+        for k in p:
+            if p[k].grad.abs().max() > 0:
+                assert _relerr(tr.named_grads()[k], p[k].grad) < 1e-4, (B, N, d, hid, use_graph, k)
