@@ -32,6 +32,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
+# bf16 MFMA products issued per fp32-equivalent multiply-add in each matrix mode
+MODE_PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16": 1}
 PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E peak
 
 
@@ -135,6 +138,10 @@ def main():
     ap.add_argument("--hid", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mst", action="store_true")
+    ap.add_argument("--matrix", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
+                    help="matrix pipe of the large encoder GEMMs: fp32 MFMA; the exact three-way bf16 split on the bf16 "
+                         "MFMA (fp32-level error, default); plain bf16 operands (loss tolerance 1e-3)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short extra runs in the other matrix modes")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying HIP graphs")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager steps after the timed region, for per-kernel HIP-event times")
     args = ap.parse_args()
@@ -159,7 +166,7 @@ def main():
     N, B, d, hid = args.nodes, args.batch, args.latent, args.hid
 
     # identical initial weights on every rank, different data per rank
-    tr = GraphVAETrainer(N, d, hid, N, device=dev, seed=0, max_batch=B, max_edges=B * N * 4)
+    tr = GraphVAETrainer(N, d, hid, N, device=dev, seed=0, max_batch=B, max_edges=B * N * 4, matrix_mode=args.matrix)
     nb = 4
     batches = [synth_graph_batch(B, N, seed=1234 + rank * 1000 + i).to(dev) for i in range(nb)]
     gen = torch.Generator().manual_seed(4321 + rank)
@@ -253,11 +260,19 @@ def main():
             traffic = None
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                    traffic = json.load(f).get("%s %d %d %d" % (name, m_, n_, k_), {}).get("traffic_bytes")
+                    traffic = json.load(f).get("%s %s %d %d %d" % (args.matrix, name, m_, n_, k_), {}).get("traffic_bytes")
             except OSError:
                 pass
-            roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel": name,
+            # the 128x128 GEMMs run on the pipe --matrix selects: price them against that pipe's peak, counting the
+            # MFMA products actually issued (six per multiply-add for the three-way split)
+            on_bf16 = args.matrix != "f32" and name.startswith("gemm128")
+            peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_F32_MFMA_TFLOPS
+            issued = ach * (MODE_PRODUCTS[args.matrix] if on_bf16 else 1)
+            roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s",
+                    "frac": issued / peak, "traffic": traffic, "kernel": name,
+                    "pipe": ("v_mfma_f32_32x32x16_bf16, %d products per fp32 multiply-add" % MODE_PRODUCTS[args.matrix])
+                            if on_bf16 else "v_mfma_f32_32x32x2_f32",
+                    "fp32_equivalent_tflops": ach,
                     "launch": {"M": m_, "N": n_, "K": k_, "flops": fl, "avg_ms": avg_ms, "launches": cnt,
                                "stored_rows": eff_rows if ":" in name else None,
                                "timed_with": "HIP events on the launch stream, %s" % (
@@ -272,11 +287,18 @@ def main():
                        "training graphs/sec (whole node) at N=%d nodes, batch %d (not the headline configuration)" % (N, B)),
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if args.matrix == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "%ssynthetic AMR-shaped graphs N<=%d (padded to %d), batch %d per GPU, "
                                    "latent d=%d, mlp_hid=%d, graph-only step: recon + kl_w*KL, full backward, Adam" % (
                                        "BASELINE configs[2]: " if (N, B, d, hid) == (64, 512, 512, 512) else "", N, N, B, d, hid),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "hip_graph": bool(use_graph)},
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "hip_graph": bool(use_graph),
+                       "matrix_pipe": {"f32": "fp32 MFMA everywhere",
+                                       "bf16x3": "fp32 operands and results; the large encoder GEMMs split every operand "
+                                                 "exactly into three bf16 pieces and sum six piece products on the bf16 MFMA "
+                                                 "with fp32 accumulation (error vs float64 equal to the fp32 MFMA's; the "
+                                                 "parity tests run at the fp32 tolerances in this mode)",
+                                       "bf16": "large encoder GEMMs on bf16-rounded operands, fp32 accumulation "
+                                               "(loss tolerance 1e-3)"}[args.matrix]},
             "step_algorithmic_tflops": step_tflops,
             "step_frac_of_f32_mfma_peak": step_tflops / (PEAK_F32_MFMA_TFLOPS * world),
             "encoder_rows": {"padded": B * N, "stored_mean": eff_rows},
@@ -284,6 +306,26 @@ def main():
             "roofline": roof,
             "gemm_kernels": kern,
         }
+        if world == 1 and not args.no_alt:
+            # the same loop in the other matrix modes (short, after the headline measurement)
+            alt = {}
+            for mode in ("f32", "bf16x3", "bf16"):
+                if mode == args.matrix:
+                    continue
+                tr.matrix_mode = _lib.matrix_mode(mode)
+                tr._graph = None
+                for i in range(5):
+                    one_step(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(30):
+                    one_step(i)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 30
+                alt[mode] = {"ms_per_step": dt * 1e3, "graphs_per_s": B / dt}
+            tr.matrix_mode = _lib.matrix_mode(args.matrix)
+            tr._graph = None
+            line["other_matrix_modes"] = alt
         if world == 1 and not args.no_mst:
             line["mst"] = mst_bench(dev, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:

@@ -7,5 +7,7 @@ surface on top of it.
 from .maxspantree import mst_graph, mst_graph_batched  # noqa: F401
 from .graph_vae import GraphVAE, VGAE_encoder, MLP_VAE_plain  # noqa: F401
 from .gtvae import GTVAE  # noqa: F401
+from ._lib import set_default_matrix_mode  # noqa: F401
 
-__all__ = ["GraphVAE", "VGAE_encoder", "MLP_VAE_plain", "GTVAE", "mst_graph", "mst_graph_batched"]
+__all__ = ["GraphVAE", "VGAE_encoder", "MLP_VAE_plain", "GTVAE", "mst_graph", "mst_graph_batched",
+           "set_default_matrix_mode"]

@@ -30,13 +30,13 @@ _SIGS = {
     "gtg_edge_prf": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P]),
     "gtg_adj_build": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, _P]),
     "gtg_encoder_fwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
-    "gtg_encoder_fwd": (c_int, [_P] * 6 + [c_int64, c_int, c_int, c_int] + [_P] * 3 + [_P, c_size_t, _P]),
+    "gtg_encoder_fwd": (c_int, [_P] * 6 + [c_int64, c_int, c_int, c_int] + [_P] * 3 + [c_int, _P, c_size_t, _P]),
     "gtg_encoder_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
-    "gtg_encoder_bwd": (c_int, [_P] * 7 + [c_int64, c_int, c_int, c_int] + [_P] * 4 + [_P, c_size_t, _P]),
+    "gtg_encoder_bwd": (c_int, [_P] * 7 + [c_int64, c_int, c_int, c_int] + [_P] * 4 + [c_int, _P, c_size_t, _P]),
     "gtg_encoder_compact_fwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "gtg_encoder_compact_fwd": (c_int, [_P] * 6 + [c_int64, c_int, c_int] + [_P] * 5 + [_P, c_size_t, _P]),
+    "gtg_encoder_compact_fwd": (c_int, [_P] * 6 + [c_int64, c_int, c_int] + [_P] * 5 + [c_int, _P, c_size_t, _P]),
     "gtg_encoder_compact_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "gtg_encoder_compact_bwd": (c_int, [_P] * 7 + [c_int64, c_int, c_int] + [_P] * 4 + [_P, c_size_t, _P]),
+    "gtg_encoder_compact_bwd": (c_int, [_P] * 7 + [c_int64, c_int, c_int] + [_P] * 4 + [c_int, _P, c_size_t, _P]),
     "gtg_latent_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "gtg_latent_fwd": (c_int, [_P] * 6 + [c_int64, c_int] + [_P] * 4 + [_P, c_size_t, _P]),
     "gtg_latent_bwd": (c_int, [_P] * 7 + [c_float, _P, c_int64, c_int] + [_P] * 5 + [_P, c_size_t, _P]),
@@ -49,13 +49,37 @@ _SIGS = {
     "gtg_decoder_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "gtg_decoder_bwd": (c_int, [_P] * 7 + [c_int, c_float, _P, c_int64, c_int, c_int, c_int] + [_P] * 5 + [_P, c_size_t, _P]),
     "gtg_adam_step": (c_int, [_P] * 4 + [c_int64, _P, c_float, c_float, c_float, c_float, c_float, _P]),
-    "gtg_gemm_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, c_int, _P, c_int, _P, c_size_t, _P]),
+    "gtg_gemm_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, c_int, _P, c_int, _P, c_size_t, c_int, _P]),
     "gtg_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gtg_gemm_rows_workspace_bytes": (c_size_t, []),
-    "gtg_gemm_f32_rows": (c_int, [_P] * 3 + [c_int] * 8 + [_P, c_int, _P, c_int, _P, _P, c_size_t, _P]),
+    "gtg_gemm_f32_rows": (c_int, [_P] * 3 + [c_int] * 8 + [_P, c_int, _P, c_int, _P, c_int, _P, c_size_t, _P]),
 }
 
 EXPORTS = tuple(_SIGS)
+
+# Matrix pipe of the large encoder GEMMs (include/gtgvae.h, GTG_MATRIX_*).  "bf16x3" splits every fp32
+# operand exactly into three bf16 pieces and runs six products on the bf16 matrix cores with fp32
+# accumulation: the same error as the fp32 pipe at 1.5x its speed, hence the default.
+MATRIX_MODES = {"f32": 0, "bf16": 1, "bf16x3": 3}
+_default_matrix_mode = MATRIX_MODES[os.environ.get("GTG_MATRIX_MODE", "bf16x3")]
+
+
+def matrix_mode(mode=None) -> int:
+    """The GTG_MATRIX_* code of ``mode`` ("f32" | "bf16x3" | "bf16" | code | None = the default)."""
+    if mode is None:
+        return _default_matrix_mode
+    if isinstance(mode, str):
+        if mode not in MATRIX_MODES:
+            raise GtgError("matrix mode must be one of %s" % sorted(MATRIX_MODES))
+        return MATRIX_MODES[mode]
+    if int(mode) not in MATRIX_MODES.values():
+        raise GtgError("matrix mode must be one of %s" % sorted(MATRIX_MODES))
+    return int(mode)
+
+
+def set_default_matrix_mode(mode) -> None:
+    global _default_matrix_mode
+    _default_matrix_mode = matrix_mode(mode)
 
 
 def lib():

@@ -225,8 +225,10 @@ size_t gtg_encoder_fwd_workspace_bytes(int64_t num_graphs, int n, int f, int d, 
 
 int gtg_encoder_fwd(const float* adj, const float* x, const float* W1, const float* b1, const float* W2,
                     const float* b2, int64_t num_graphs, int n, int f, int d, float* h1, float* pooled,
-                    int32_t* argmax, void* ws, size_t ws_bytes, void* stream)
+                    int32_t* argmax, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(num_graphs >= 0 && f >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
     GTG_REQUIRE(x != nullptr || f == n, "identity node features need input_dim == n");
@@ -310,8 +312,10 @@ size_t gtg_encoder_bwd_workspace_bytes(int64_t num_graphs, int n, int f, int d, 
 
 int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const float* W2, const float* h1,
                     const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int f, int d, float* dW1,
-                    float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, void* stream)
+                    float* db1, float* dW2, float* db2, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
     (void)W1;
     GTG_REQUIRE(num_graphs >= 1 && f >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
@@ -409,8 +413,10 @@ size_t gtg_encoder_compact_fwd_workspace_bytes(int64_t num_graphs, int n, int d)
 
 int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float* W1, const float* b1, const float* W2,
                             const float* b2, int64_t num_graphs, int n, int d, int32_t* meta, float* adjc, float* h1c,
-                            float* pooled, int32_t* argmax, void* ws, size_t ws_bytes, void* stream)
+                            float* pooled, int32_t* argmax, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
     GTG_REQUIRE(adj && counts && W1 && b1 && W2 && b2 && meta && adjc && h1c && pooled && argmax, "null pointer");
@@ -491,8 +497,10 @@ size_t gtg_encoder_compact_bwd_workspace_bytes(int64_t num_graphs, int n, int d)
 
 int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* meta, const float* W2, const float* h1c,
                             const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int d, float* dW1,
-                            float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, void* stream)
+                            float* db1, float* dW2, float* db2, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
     GTG_REQUIRE(adj && adjc && meta && W2 && h1c && argmax && dpooled && dW1 && db1 && dW2 && db2, "null pointer");
@@ -772,8 +780,10 @@ int gtg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 // Plain GEMM entry (tests, and callers that want one of the three layouts).
 int gtg_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
                  int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, void* slabs,
-                 size_t slab_bytes, void* stream)
+                 size_t slab_bytes, int matrix_mode, void* stream)
 {
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_ACCUM, "unsupported epilogue");
     GemmDesc g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -802,8 +812,10 @@ size_t gtg_gemm_rows_workspace_bytes(void)
 
 int gtg_gemm_f32_rows(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
                       int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, const int32_t* rows_dev,
-                      void* ws, size_t ws_bytes, void* stream)
+                      int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_ACCUM, "unsupported epilogue");
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);

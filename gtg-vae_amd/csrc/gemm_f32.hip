@@ -16,8 +16,11 @@
 #include "gtg_internal.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace gtg {
+
+thread_local int g_matrix_mode = GTG_MATRIX_F32;
 
 namespace {
 
@@ -167,19 +170,183 @@ struct Tile {
     }
 };
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// One operand tile for the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16): ROWS x BK
+// values kept as PLANES bf16 "planes" whose sum is the fp32 value.
+//   PLANES = 1: the value rounded to bf16 (round to nearest even).
+//   PLANES = 3: an exact three-way split by truncation, x = h0 + h1 + h2 with
+//               8 significant bits each (fp32 has 24), so that the six products
+//               h_i*h_j, i + j <= 2, summed in fp32 reproduce the fp32 product
+//               to ~2^-22 relative.
+// LDS image per plane: [ROWS][BK bf16 + 16 B pad] = 80 bytes a row, K contiguous
+// for both operand layouts, so a fragment (row, 8 consecutive k) is one
+// conflict-free ds_read_b128.  Every thread owns NP pieces of (row, 8 k): two
+// 16-byte loads when K is contiguous in memory, eight dword loads (coalesced
+// across the 64 rows of a wave) when the rows are.
+template <int ROWS, bool KC, int NTHREADS, int PLANES, int TK>
+struct TileB {
+    static constexpr int ROWB = 2 * TK + 16;                   // bytes per row per plane (16 B pad)
+    static constexpr int PLANE = ROWS * ROWB / 4;              // floats per plane
+    static constexpr int SIZE = PLANES * PLANE;                // floats per tile
+    static constexpr int NP = ROWS * (TK / 8) / NTHREADS;      // pieces per thread
+    static constexpr int NV = 2 * NP;
+    static_assert(NP >= 1 && NP * NTHREADS == ROWS * (TK / 8), "tile must split evenly over the staging threads");
+
+    __device__ static __forceinline__ void piece(int p, int& row, int& kb)
+    {
+        if (KC) {
+            row = p / (TK / 8);
+            kb = p % (TK / 8);
+        } else {
+            row = p % ROWS;
+            kb = p / ROWS;
+        }
+    }
+
+    __device__ static __forceinline__ void fetch(f32x4 (&reg)[NV], const float* __restrict__ base, int ld, int row0,
+                                                 int rows_total, int k0, int k_end, bool vec, int tid)
+    {
+        const bool interior = row0 + ROWS <= rows_total && k0 + TK <= k_end;  // block-uniform
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int row, kb;
+            piece(tid + i * NTHREADS, row, kb);
+            const int gr = row0 + row, gk = k0 + 8 * kb;
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+            if (KC) {
+                const float* p = base + (long long)gr * ld + gk;
+                if (interior && vec) {
+                    lo = *reinterpret_cast<const f32x4*>(p);
+                    hi = *reinterpret_cast<const f32x4*>(p + 4);
+                } else if (gr < rows_total) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (gk + q < k_end) lo[q] = p[q];
+                        if (gk + 4 + q < k_end) hi[q] = p[4 + q];
+                    }
+                }
+            } else {
+                const float* p = base + (long long)gk * ld + gr;
+                if (interior) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        lo[q] = p[(long long)q * ld];
+                        hi[q] = p[(long long)(4 + q) * ld];
+                    }
+                } else if (gr < rows_total) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (gk + q < k_end) lo[q] = p[(long long)q * ld];
+                        if (gk + 4 + q < k_end) hi[q] = p[(long long)(4 + q) * ld];
+                    }
+                }
+            }
+            reg[2 * i] = lo;
+            reg[2 * i + 1] = hi;
+        }
+    }
+
+    // interior tile, aligned rows: no guards, no branches (the waits on these loads can then be counted)
+    __device__ static __forceinline__ void fetch_fast(f32x4 (&reg)[NV], const float* __restrict__ base, int ld, int row0,
+                                                      int k0, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int row, kb;
+            piece(tid + i * NTHREADS, row, kb);
+            const int gr = row0 + row, gk = k0 + 8 * kb;
+            if (KC) {
+                const float* p = base + (long long)gr * ld + gk;
+                reg[2 * i] = *reinterpret_cast<const f32x4*>(p);
+                reg[2 * i + 1] = *reinterpret_cast<const f32x4*>(p + 4);
+            } else {
+                const float* p = base + (long long)gk * ld + gr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    reg[2 * i][q] = p[(long long)q * ld];
+                    reg[2 * i + 1][q] = p[(long long)(4 + q) * ld];
+                }
+            }
+        }
+    }
+
+    // bf16 pair (low half = x0, high half = x1) of the top 16 bits of two fp32 words
+    __device__ static __forceinline__ unsigned top_halves(float x0, float x1)
+    {
+        return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+    }
+
+    __device__ static __forceinline__ void stage(float* s, const f32x4 (&reg)[NV], int tid)
+    {
+        char* sb = reinterpret_cast<char*>(s);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int row, kb;
+            piece(tid + i * NTHREADS, row, kb);
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x[q] = reg[2 * i][q];
+                x[4 + q] = reg[2 * i + 1][q];
+            }
+            char* dst = sb + row * ROWB + kb * 16;
+            if (PLANES == 1) {
+                u32x4 w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned pk;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x[2 * q]), "v"(x[2 * q + 1]));
+                    w[q] = pk;
+                }
+                *reinterpret_cast<u32x4*>(dst) = w;
+            } else {
+                u32x4 w0, w1, w2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a0 = x[2 * q], b0 = x[2 * q + 1];
+                    w0[q] = top_halves(a0, b0);
+                    const float a1 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u);  // exact
+                    const float b1 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u);
+                    w1[q] = top_halves(a1, b1);
+                    const float a2 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);  // <= 8 bits left
+                    const float b2 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
+                    w2[q] = top_halves(a2, b2);
+                }
+                *reinterpret_cast<u32x4*>(dst) = w0;
+                *reinterpret_cast<u32x4*>(dst + PLANE * 4) = w1;
+                *reinterpret_cast<u32x4*>(dst + 2 * PLANE * 4) = w2;
+            }
+        }
+    }
+
+    // plane pl, row rbase + r, the 8 k values 16*g + 8*h .. +7
+    __device__ static __forceinline__ bf16x8 frag(const float* s, int pl, int rbase, int g, int r, int h)
+    {
+        const char* p = reinterpret_cast<const char*>(s) + pl * (PLANE * 4) + (rbase + r) * ROWB + (2 * g + h) * 16;
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+    }
+};
+
 // WAVES_M x WAVES_N waves share one BM x BN tile; KG such wave groups split the
 // block's K range between them (each with its own LDS buffers and its own
 // loads) and their accumulators are summed through LDS, in group order, before
 // the epilogue.  KG > 1 shortens the dependent load -> LDS -> MFMA chain of
 // short-and-narrow GEMMs (batch-sized M, K of a few hundred) that have too few
 // tiles to hide it behind other blocks.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC>
+// PREC selects the matrix pipe: 0 = fp32 operands (v_mfma_f32_32x32x2_f32), 1 = operands rounded to
+// bf16, 3 = the exact three-plane bf16 split with six products per k step (both on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC, int PREC>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const KArgs a)
 {
     constexpr int GT = 64 * WAVES_M * WAVES_N;  // threads of one wave group
     constexpr int GW = WAVES_M * WAVES_N;
-    using TA = Tile<BM, AKC, GT>;
-    using TB = Tile<BN, BKC, GT>;
+    // k extent of one pipeline step: the three-plane tiles take 16 so that two blocks still fit a CU's LDS
+    constexpr int KS = (PREC == 3) ? 16 : BK;
+    using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, PREC == 0 ? 1 : PREC, KS>>::type;
+    using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, PREC == 0 ? 1 : PREC, KS>>::type;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
@@ -269,11 +436,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
     }
     // every wave group runs the same number of iterations (block-wide barriers); a group whose share is
     // empty or short multiplies zero tiles
-    int nk = (k_end - k_begin + BK - 1) / BK;
+    int nk = (k_end - k_begin + KS - 1) / KS;
     if (KG > 1) {
         nk = (nk + KG - 1) / KG;
-        k_begin += kg * nk * BK;
-        k_end = min(k_end, k_begin + nk * BK);
+        k_begin += kg * nk * KS;
+        k_end = min(k_end, k_begin + nk * KS);
     }
     const float* __restrict__ A = a.A + batch * a.strideA;
     const float* __restrict__ B = a.B + batch * a.strideB + (a.off_b ? row_off * a.ldb : 0);
@@ -286,54 +453,158 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // Software pipeline: the registers ra/rb hold tile kt+1 (fetched one full
-    // iteration earlier); they are written to the idle LDS buffer after the
-    // first k group's MFMAs have been issued, and re-used at once for the
-    // fetch of tile kt+2, so the staging traffic sits in the shadow of the
-    // MFMA stream and a global load has a whole iteration to land.
-    f32x4 ra[TA::NV], rb[TB::NV];
-    if (nk > 0) {
-        TA::fetch(ra, A, a.lda, m0, Mr, k_begin, k_end, a.vecA, tid);
-        TB::fetch(rb, B, a.ldb, n0, a.N, k_begin, k_end, a.vecB, tid);
-        TA::stage(sA0, ra, tid);
-        TB::stage(sB0, rb, tid);
-        if (nk > 1) {
-            TA::fetch(ra, A, a.lda, m0, Mr, k_begin + BK, k_end, a.vecA, tid);
-            TB::fetch(rb, B, a.ldb, n0, a.N, k_begin + BK, k_end, a.vecB, tid);
-        }
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const float* cA = (kt & 1) ? sA1 : sA0;
-        const float* cB = (kt & 1) ? sB1 : sB0;
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = TA::frag(cA, wm + 32 * i, g, r, h);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = TB::frag(cB, wn + 32 * j, g, r, h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-            if (g == 0) {
-                if (kt + 1 < nk) {
-                    TA::stage((kt & 1) ? sA0 : sA1, ra, tid);
-                    TB::stage((kt & 1) ? sB0 : sB1, rb, tid);
-                }
-                if (kt + 2 < nk) {
-                    const int k0 = k_begin + (kt + 2) * BK;
-                    TA::fetch(ra, A, a.lda, m0, Mr, k0, k_end, a.vecA, tid);
-                    TB::fetch(rb, B, a.ldb, n0, a.N, k0, k_end, a.vecB, tid);
-                }
+    if constexpr (PREC == 0) {
+        // Software pipeline: the registers ra/rb hold tile kt+1 (fetched one full
+        // iteration earlier); they are written to the idle LDS buffer after the
+        // first k group's MFMAs have been issued, and re-used at once for the
+        // fetch of tile kt+2, so the staging traffic sits in the shadow of the
+        // MFMA stream and a global load has a whole iteration to land.
+        f32x4 ra[TA::NV], rb[TB::NV];
+        if (nk > 0) {
+            TA::fetch(ra, A, a.lda, m0, Mr, k_begin, k_end, a.vecA, tid);
+            TB::fetch(rb, B, a.ldb, n0, a.N, k_begin, k_end, a.vecB, tid);
+            TA::stage(sA0, ra, tid);
+            TB::stage(sB0, rb, tid);
+            if (nk > 1) {
+                TA::fetch(ra, A, a.lda, m0, Mr, k_begin + KS, k_end, a.vecA, tid);
+                TB::fetch(rb, B, a.ldb, n0, a.N, k_begin + KS, k_end, a.vecB, tid);
             }
         }
         __syncthreads();
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const float* cA = (kt & 1) ? sA1 : sA0;
+            const float* cB = (kt & 1) ? sB1 : sB0;
+#pragma unroll
+            for (int g = 0; g < BK / 8; ++g) {
+                f32x4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = TA::frag(cA, wm + 32 * i, g, r, h);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = TB::frag(cB, wn + 32 * j, g, r, h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                if (g == 0) {
+                    if (kt + 1 < nk) {
+                        TA::stage((kt & 1) ? sA0 : sA1, ra, tid);
+                        TB::stage((kt & 1) ? sB0 : sB1, rb, tid);
+                    }
+                    if (kt + 2 < nk) {
+                        const int k0 = k_begin + (kt + 2) * BK;
+                        TA::fetch(ra, A, a.lda, m0, Mr, k0, k_end, a.vecA, tid);
+                        TB::fetch(rb, B, a.ldb, n0, a.N, k0, k_end, a.vecB, tid);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // The bf16 pipes finish a k step in a fraction of a global load's latency, so the register stage is a
+        // ring of DEPTH tiles: tile t waits in slot t % DEPTH, is split into planes and written to LDS buffer
+        // t & 1 during step t - 1, and its slot is refilled at once with tile t + DEPTH.  The loop is unrolled
+        // by DEPTH so that the slots are fixed registers.  Interior tiles (whole rows, whole k steps, aligned)
+        // run a copy of the loop without a single guard or branch in the step, so that the compiler can count
+        // the outstanding loads instead of draining them and can place the split arithmetic between the MFMAs.
+        constexpr int PL = PREC;
+        constexpr int DEPTH = 3;
+        f32x4 ra[DEPTH][TA::NV], rb[DEPTH][TB::NV];
+        const bool fast = m0 + BM <= Mr && n0 + BN <= a.N && (k_end - k_begin) % KS == 0 && nk > 0 &&
+                          (!AKC || a.vecA) && (!BKC || a.vecB);
+        auto step = [&](auto fast_tag, int kt, auto slot_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            constexpr int slot = decltype(slot_tag)::value;
+            const float* cA = (kt & 1) ? sA1 : sA0;
+            const float* cB = (kt & 1) ? sB1 : sB0;
+#pragma unroll
+            for (int g = 0; g < KS / 16; ++g) {
+                bf16x8 fa[TM][PL], fb[TN][PL];
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i][pl] = TA::frag(cA, pl, wm + 32 * i, g, r, h);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j][pl] = TB::frag(cB, pl, wn + 32 * j, g, r, h);
+                }
+                // products of plane pairs (pa, pb) with pa + pb < PL, the small ones first
+#pragma unroll
+                for (int sum = PL - 1; sum >= 0; --sum)
+#pragma unroll
+                    for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j],
+                                                                                  0, 0, 0);
+                if (g == 0) {
+                    // tile kt + 1 waits in `slot`; staging is unconditional (past the last tile it rewrites
+                    // a buffer nobody reads again)
+                    TA::stage((kt & 1) ? sA0 : sA1, ra[slot], tid);
+                    TB::stage((kt & 1) ? sB0 : sB1, rb[slot], tid);
+                    if (FAST) {
+                        if (PL == 3) {
+                            // one MFMA, then four of the split's vector instructions in its shadow
+#pragma unroll
+                            for (int q = 0; q < 6 * TM * TN; ++q) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            }
+                        }
+                        // past the end the last tile is fetched again (never staged): no branch
+                        const int k0 = k_begin + min(kt + 1 + DEPTH, nk - 1) * KS;
+                        TA::fetch_fast(ra[slot], A, a.lda, m0, k0, tid);
+                        TB::fetch_fast(rb[slot], B, a.ldb, n0, k0, tid);
+                    } else if (kt + 1 + DEPTH < nk) {
+                        const int k0 = k_begin + (kt + 1 + DEPTH) * KS;
+                        TA::fetch(ra[slot], A, a.lda, m0, Mr, k0, k_end, a.vecA, tid);
+                        TB::fetch(rb[slot], B, a.ldb, n0, a.N, k0, k_end, a.vecB, tid);
+                    }
+                }
+            }
+            __syncthreads();
+        };
+        auto run = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+            for (int t = 0; t < DEPTH; ++t) {
+                if (FAST) {
+                    const int k0 = k_begin + min(t, nk - 1) * KS;
+                    TA::fetch_fast(ra[t], A, a.lda, m0, k0, tid);
+                    TB::fetch_fast(rb[t], B, a.ldb, n0, k0, tid);
+                } else if (t < nk) {
+                    TA::fetch(ra[t], A, a.lda, m0, Mr, k_begin + t * KS, k_end, a.vecA, tid);
+                    TB::fetch(rb[t], B, a.ldb, n0, a.N, k_begin + t * KS, k_end, a.vecB, tid);
+                }
+            }
+            if (nk > 0) {
+                TA::stage(sA0, ra[0], tid);
+                TB::stage(sB0, rb[0], tid);
+                if (FAST) {
+                    const int k0 = k_begin + min(DEPTH, nk - 1) * KS;
+                    TA::fetch_fast(ra[0], A, a.lda, m0, k0, tid);
+                    TB::fetch_fast(rb[0], B, a.ldb, n0, k0, tid);
+                } else if (DEPTH < nk) {
+                    TA::fetch(ra[0], A, a.lda, m0, Mr, k_begin + DEPTH * KS, k_end, a.vecA, tid);
+                    TB::fetch(rb[0], B, a.ldb, n0, a.N, k_begin + DEPTH * KS, k_end, a.vecB, tid);
+                }
+            }
+            __syncthreads();
+            for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
+                if (kt0 < nk) step(fast_tag, kt0, std::integral_constant<int, 1 % DEPTH>());
+                if (kt0 + 1 < nk) step(fast_tag, kt0 + 1, std::integral_constant<int, 2 % DEPTH>());
+                if (kt0 + 2 < nk) step(fast_tag, kt0 + 2, std::integral_constant<int, 3 % DEPTH>());
+            }
+        };
+        static_assert(DEPTH == 3, "the step calls above are written out for a ring of three");
+        if (fast)
+            run(std::true_type());
+        else
+            run(std::false_type());
     }
 
     // ---- epilogue.  Accumulator register e of lane (r,h) is element
@@ -569,16 +840,16 @@ inline void cfg_dims(TileCfg c, int& bm, int& bn)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KG>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, int PREC = 0>
 int launch_cfg(const KArgs& k, bool akc, bool bkc, int grid, hipStream_t s)
 {
     const dim3 block(64 * WAVES_M * WAVES_N * KG);
     if (akc && bkc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, KG, true, true>), dim3(grid), block, 0, s, k);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, KG, true, true, PREC>), dim3(grid), block, 0, s, k);
     else if (akc && !bkc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, KG, true, false>), dim3(grid), block, 0, s, k);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, KG, true, false, PREC>), dim3(grid), block, 0, s, k);
     else if (!akc && !bkc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, KG, false, false>), dim3(grid), block, 0, s, k);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, KG, false, false, PREC>), dim3(grid), block, 0, s, k);
     else
         return set_error(GTG_ERR_UNSUPPORTED, "gemm: A M-contiguous with B K-contiguous is not instantiated");
     return check_launch("gemm_kernel");
@@ -726,9 +997,19 @@ int gemm(const GemmDesc& d, hipStream_t s)
     char tag[32];
     snprintf(tag, sizeof(tag), "%s%s", kNames[(int)cfg][lay], d.m_dev ? ":m" : d.k_dev ? ":k" : d.batch_dim ? ":g" : "");
     ProfScope prof(s, tag, (long long)d.M * d.batch, d.N, d.K);
+    // the matrix pipe applies to the 128x128 configuration (the MFMA-bound GEMMs); the small-tile
+    // configurations are latency-bound and stay on the fp32 pipe
+    const int prec = (cfg == CFG_128) ? g_matrix_mode : 0;
     int rc;
     switch (cfg) {
-        case CFG_128: rc = launch_cfg<128, 128, 2, 2, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        case CFG_128:
+            if (prec == 3)
+                rc = launch_cfg<128, 128, 2, 2, 1, 3>(k, d.a_kc, d.b_kc, (int)grid, s);
+            else if (prec == 1)
+                rc = launch_cfg<128, 128, 2, 2, 1, 1>(k, d.a_kc, d.b_kc, (int)grid, s);
+            else
+                rc = launch_cfg<128, 128, 2, 2, 1>(k, d.a_kc, d.b_kc, (int)grid, s);
+            break;
         case CFG_64x128: rc = launch_cfg<64, 128, 1, 4, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;
         case CFG_64_K2: rc = launch_cfg<64, 64, 2, 2, 2>(k, d.a_kc, d.b_kc, (int)grid, s); break;
         case CFG_32_K4: rc = launch_cfg<32, 32, 1, 1, 4>(k, d.a_kc, d.b_kc, (int)grid, s); break;

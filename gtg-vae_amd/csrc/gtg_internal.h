@@ -76,6 +76,18 @@ struct GemmDesc {
     int32_t* tail_counters = nullptr;
 };
 
+// Matrix pipe of the MFMA-bound (128x128-tile) GEMMs issued by the calling thread: GTG_MATRIX_F32
+// (v_mfma_f32_32x32x2_f32), GTG_MATRIX_BF16 (operands rounded to bf16) or GTG_MATRIX_BF16X3 (exact
+// three-way bf16 split of both operands, six products per k step, fp32 accumulate: fp32-level error).
+// An entry point that takes a matrix_mode argument holds a MatrixModeScope for its duration.
+extern thread_local int g_matrix_mode;
+struct MatrixModeScope {
+    int prev;
+    explicit MatrixModeScope(int mode) : prev(g_matrix_mode) { g_matrix_mode = mode; }
+    ~MatrixModeScope() { g_matrix_mode = prev; }
+};
+inline bool matrix_mode_valid(int m) { return m == GTG_MATRIX_F32 || m == GTG_MATRIX_BF16 || m == GTG_MATRIX_BF16X3; }
+
 // Tail-split workspace: *ws_bytes of float slabs and *counter_bytes of int32 counters.
 void gemm_tail_workspace(size_t* ws_bytes, size_t* counter_bytes);
 

@@ -57,8 +57,9 @@ class EncoderFn(torch.autograd.Function):
     """pooled (B, d) = global_max_pool(GCN2(relu(GCN1(x))))."""
 
     @staticmethod
-    def forward(ctx, adj, x, W1, b1, W2, b2, counts=None):
+    def forward(ctx, adj, x, W1, b1, W2, b2, counts=None, matrix_mode=None):
         L = _lib.lib()
+        ctx.mode = mode = _lib.matrix_mode(matrix_mode)
         adj, x, W1, b1, W2, b2 = map(_f32c, (adj, x, W1, b1, W2, b2))
         B, n, _ = adj.shape
         H, f = W1.shape
@@ -78,7 +79,7 @@ class EncoderFn(torch.autograd.Function):
             argmax = torch.empty((B, d), dtype=torch.int32, device=dev)
             ws = _ws(L.gtg_encoder_compact_fwd_workspace_bytes(B, n, d), dev)
             check(L.gtg_encoder_compact_fwd(ptr(adj), ptr(counts), ptr(W1), ptr(b1), ptr(W2), ptr(b2), B, n, d,
-                                            ptr(meta), ptr(adjc), ptr(h1c), ptr(pooled), ptr(argmax), ptr(ws),
+                                            ptr(meta), ptr(adjc), ptr(h1c), ptr(pooled), ptr(argmax), mode, ptr(ws),
                                             ws.numel(), stream_ptr()), "gtg_encoder_compact_fwd")
             ctx.save_for_backward(adj, adjc, meta, W2, h1c, argmax)
             ctx.dims = (B, n, f, d)
@@ -90,7 +91,7 @@ class EncoderFn(torch.autograd.Function):
         nb = L.gtg_encoder_fwd_workspace_bytes(B, n, f, d, int(x is not None))
         ws = _ws(nb, dev)
         check(L.gtg_encoder_fwd(ptr(adj), ptr(x), ptr(W1), ptr(b1), ptr(W2), ptr(b2), B, n, f, d, ptr(h1), ptr(pooled),
-                                ptr(argmax), ptr(ws), ws.numel(), stream_ptr()), "gtg_encoder_fwd")
+                                ptr(argmax), mode, ptr(ws), ws.numel(), stream_ptr()), "gtg_encoder_fwd")
         ctx.save_for_backward(adj, x, W1, W2, h1, argmax)
         ctx.dims = (B, n, f, d)
         ctx.mark_non_differentiable(argmax)
@@ -110,17 +111,17 @@ class EncoderFn(torch.autograd.Function):
             adj, adjc, meta, W2, h1c, argmax = ctx.saved_tensors
             ws = _ws(L.gtg_encoder_compact_bwd_workspace_bytes(B, n, d), dev)
             check(L.gtg_encoder_compact_bwd(ptr(adj), ptr(adjc), ptr(meta), ptr(W2), ptr(h1c), ptr(argmax),
-                                            ptr(dpooled), B, n, d, ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(ws),
-                                            ws.numel(), stream_ptr()), "gtg_encoder_compact_bwd")
-            return None, None, dW1, db1, dW2, db2, None
+                                            ptr(dpooled), B, n, d, ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ctx.mode,
+                                            ptr(ws), ws.numel(), stream_ptr()), "gtg_encoder_compact_bwd")
+            return None, None, dW1, db1, dW2, db2, None, None
         adj, x, W1, W2, h1, argmax = ctx.saved_tensors
         nb = L.gtg_encoder_bwd_workspace_bytes(B, n, f, d, int(x is not None))
         ws = _ws(nb, dev)
         check(L.gtg_encoder_bwd(ptr(adj), ptr(x), ptr(W1), ptr(W2), ptr(h1), ptr(argmax), ptr(dpooled), B, n, f, d,
-                                ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(ws), ws.numel(), stream_ptr()),
+                                ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ctx.mode, ptr(ws), ws.numel(), stream_ptr()),
               "gtg_encoder_bwd")
         # node features and the adjacency are inputs, not parameters: no gradient
-        return None, None, dW1, db1, dW2, db2, None
+        return None, None, dW1, db1, dW2, db2, None, None
 
 
 # ---------------------------------------------------------------------------
@@ -280,7 +281,7 @@ def edge_precision_recall(edges: torch.Tensor, count: torch.Tensor, gold_bits: t
 
 
 def gemm(A, B, a_kc=True, b_kc=True, bias=None, epilogue=0, aux=None, out=None, M=None, N=None, K=None,
-         split_k=True):
+         split_k=True, matrix_mode="f32"):
     """Thin test/profiling hook over gtg_gemm_f32 (see include/gtgvae.h)."""
     L = _lib.lib()
     A, B = _f32c(A), _f32c(B)
@@ -294,11 +295,11 @@ def gemm(A, B, a_kc=True, b_kc=True, bias=None, epilogue=0, aux=None, out=None, 
         slabs = _ws(nb, A.device)
     check(L.gtg_gemm_f32(ptr(A), ptr(B), ptr(C), M, N, K, A.stride(0), B.stride(0), C.stride(0), int(a_kc), int(b_kc),
                          ptr(_f32c(bias)), epilogue, ptr(_f32c(aux)), aux.stride(0) if aux is not None else 0,
-                         ptr(slabs), nb, stream_ptr()), "gtg_gemm_f32")
+                         ptr(slabs), nb, _lib.matrix_mode(matrix_mode), stream_ptr()), "gtg_gemm_f32")
     return C
 
 
-def gemm_rows(A, B, a_kc=True, b_kc=True, rows_dev=None, bias=None, epilogue=0, aux=None, out=None):
+def gemm_rows(A, B, a_kc=True, b_kc=True, rows_dev=None, bias=None, epilogue=0, aux=None, out=None, matrix_mode="f32"):
     """Test/profiling hook over gtg_gemm_f32_rows: the GEMM of the compact-row
     encoder (row count read on the device, tail tiles split along K)."""
     L = _lib.lib()
@@ -309,6 +310,7 @@ def gemm_rows(A, B, a_kc=True, b_kc=True, rows_dev=None, bias=None, epilogue=0, 
     ws = _ws(L.gtg_gemm_rows_workspace_bytes(), A.device)
     check(L.gtg_gemm_f32_rows(ptr(A), ptr(B), ptr(C), M, N, K, A.stride(0), B.stride(0), C.stride(0), int(a_kc),
                               int(b_kc), ptr(_f32c(bias)), epilogue, ptr(_f32c(aux)),
-                              aux.stride(0) if aux is not None else 0, ptr(rows_dev), ptr(ws), ws.numel(), stream_ptr()),
+                              aux.stride(0) if aux is not None else 0, ptr(rows_dev), _lib.matrix_mode(matrix_mode),
+                              ptr(ws), ws.numel(), stream_ptr()),
           "gtg_gemm_f32_rows")
     return C

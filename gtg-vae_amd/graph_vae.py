@@ -70,7 +70,8 @@ class VGAE_encoder(nn.Module):
         if adj is None:
             adj, counts = Fn.build_adj(edge_index, num_graphs, nmax, return_counts=True)
         pooled, self.last_argmax = Fn.EncoderFn.apply(adj, x, self.conv1.lin.weight, self.conv1.bias,
-                                                      self.conv2.lin.weight, self.conv2.bias, counts)
+                                                      self.conv2.lin.weight, self.conv2.bias, counts,
+                                                      getattr(self, "matrix_mode", None))
         return pooled
 
 

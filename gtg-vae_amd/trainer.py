@@ -45,7 +45,8 @@ def _align(n: int, a: int = 64) -> int:
 class GraphVAETrainer:
     def __init__(self, input_dim: int, latent_dim: int, mlp_hid_dim: int, nmax: int, device="cuda",
                  init: Optional[Dict[str, torch.Tensor]] = None, lr: float = 1e-3, betas=(0.5, 0.999),
-                 eps: float = 1e-8, max_batch: int = 0, max_edges: int = 0, group=None, seed: int = 0):
+                 eps: float = 1e-8, max_batch: int = 0, max_edges: int = 0, group=None, seed: int = 0,
+                 matrix_mode=None):
         if nmax > 64:
             raise _lib.GtgError("nmax > 64 is not supported")
         if input_dim != nmax:
@@ -57,6 +58,8 @@ class GraphVAETrainer:
         self.f, self.d, self.hid, self.n = input_dim, latent_dim, mlp_hid_dim, nmax
         self.m = nmax * (nmax + 1) // 2
         self.lr, self.betas, self.eps = lr, betas, eps
+        # matrix pipe of the large encoder GEMMs: "f32" | "bf16x3" (fp32-accurate, the default) | "bf16"
+        self.matrix_mode = _lib.matrix_mode(matrix_mode)
 
         # ---- flat parameter / gradient / moment buffers -----------------------
         self.offsets: Dict[str, tuple] = {}
@@ -185,7 +188,7 @@ class GraphVAETrainer:
         check(L.gtg_encoder_compact_fwd(ptr(self.adj), ptr(self.counts), ptr(p["encoder.conv1.lin.weight"]),
                                         ptr(p["encoder.conv1.bias"]), ptr(p["encoder.conv2.lin.weight"]),
                                         ptr(p["encoder.conv2.bias"]), B, n, d, ptr(meta), ptr(self.adjc), ptr(self.h1),
-                                        ptr(self.pooled), ptr(self.argmax), ws, wsn, stream),
+                                        ptr(self.pooled), ptr(self.argmax), self.matrix_mode, ws, wsn, stream),
               "gtg_encoder_compact_fwd")
         check(L.gtg_latent_fwd(ptr(self.pooled), ptr(p["zg_mu.weight"]), ptr(p["zg_mu.bias"]), ptr(p["zg_var.weight"]),
                                ptr(p["zg_var.bias"]), ptr(self.eps_buf), B, d, ptr(self.mu), ptr(self.logvar),
@@ -218,8 +221,8 @@ class GraphVAETrainer:
         check(L.gtg_encoder_compact_bwd(ptr(self.adj), ptr(self.adjc), ptr(meta), ptr(p["encoder.conv2.lin.weight"]),
                                         ptr(self.h1), ptr(self.argmax), ptr(self.dh), B, n, d,
                                         ptr(g["encoder.conv1.lin.weight"]), ptr(g["encoder.conv1.bias"]),
-                                        ptr(g["encoder.conv2.lin.weight"]), ptr(g["encoder.conv2.bias"]), ptr(self.ws),
-                                        self.ws.numel(), stream), "gtg_encoder_compact_bwd")
+                                        ptr(g["encoder.conv2.lin.weight"]), ptr(g["encoder.conv2.bias"]), self.matrix_mode,
+                                        ptr(self.ws), self.ws.numel(), stream), "gtg_encoder_compact_bwd")
 
     def _seg_adam(self, stream: int):
         check(self.L.gtg_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),

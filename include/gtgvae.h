@@ -37,6 +37,21 @@ extern "C" {
 #define GTG_ERR_UNSUPPORTED (-3)
 #define GTG_ERR_WORKSPACE (-4)
 
+/* Matrix pipe for the large (MFMA-bound) GEMMs of an entry point that takes a
+ * `matrix_mode` argument.  Operands and results are fp32 in memory in every mode.
+ *   GTG_MATRIX_F32     v_mfma_f32_32x32x2_f32 on the fp32 operands
+ *   GTG_MATRIX_BF16X3  every operand value is split exactly into three bf16 pieces
+ *                      (8 + 8 + 8 significant bits) on its way into LDS and the six
+ *                      piece products of weight >= 2^-16 run on
+ *                      v_mfma_f32_32x32x16_bf16 with fp32 accumulation: the error
+ *                      against float64 equals the fp32 pipe's (about 1e-6 of max|C|),
+ *                      at 1.5x its speed.  Inf operands give NaN (inf - inf in the split).
+ *   GTG_MATRIX_BF16    operands rounded to bf16 (round to nearest even), one product:
+ *                      about 3e-3 of max|C|; for loss tolerances of 1e-3. */
+#define GTG_MATRIX_F32 0
+#define GTG_MATRIX_BF16 1
+#define GTG_MATRIX_BF16X3 3
+
 int gtg_version(void);
 const char* gtg_last_error(void);
 int gtg_max_nodes(void);
@@ -91,11 +106,11 @@ int gtg_adj_build(const int64_t* edge_index, int64_t num_edges, int64_t num_grap
 size_t gtg_encoder_fwd_workspace_bytes(int64_t num_graphs, int n, int f, int d, int has_x);
 int gtg_encoder_fwd(const float* adj, const float* x, const float* W1, const float* b1, const float* W2,
                     const float* b2, int64_t num_graphs, int n, int f, int d, float* h1, float* pooled,
-                    int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+                    int32_t* argmax, int matrix_mode, void* ws, size_t ws_bytes, void* stream);
 size_t gtg_encoder_bwd_workspace_bytes(int64_t num_graphs, int n, int f, int d, int has_x);
 int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const float* W2, const float* h1,
                     const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int f, int d, float* dW1,
-                    float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, void* stream);
+                    float* db1, float* dW2, float* db2, int matrix_mode, void* ws, size_t ws_bytes, void* stream);
 
 /* Encoder on compact node rows, identity node features only (x = I_n, f == n).
  * Rows [0, n_b) of graph b are stored back to back (n_b = 1 + the highest node
@@ -112,11 +127,11 @@ int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const flo
 size_t gtg_encoder_compact_fwd_workspace_bytes(int64_t num_graphs, int n, int d);
 int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float* W1, const float* b1, const float* W2,
                             const float* b2, int64_t num_graphs, int n, int d, int32_t* meta, float* adjc, float* h1c,
-                            float* pooled, int32_t* argmax, void* ws, size_t ws_bytes, void* stream);
+                            float* pooled, int32_t* argmax, int matrix_mode, void* ws, size_t ws_bytes, void* stream);
 size_t gtg_encoder_compact_bwd_workspace_bytes(int64_t num_graphs, int n, int d);
 int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* meta, const float* W2, const float* h1c,
                             const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int d, float* dW1,
-                            float* db1, float* dW2, float* db2, void* ws, size_t ws_bytes, void* stream);
+                            float* db1, float* dW2, float* db2, int matrix_mode, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- latent head ---------------------------------------------------------
  * Replaces zg_mu / zg_var (src/gtvae.py:25-26,108-109), reparameterize
@@ -180,7 +195,7 @@ int gtg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * slabs (optional) enables ordered split-K for short-and-wide shapes. */
 int gtg_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
                  int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, void* slabs,
-                 size_t slab_bytes, void* stream);
+                 size_t slab_bytes, int matrix_mode, void* stream);
 size_t gtg_gemm_splitk_workspace_bytes(int M, int N, int K);
 
 /* The same GEMM with the row count read on the device: only the first
@@ -192,7 +207,7 @@ size_t gtg_gemm_splitk_workspace_bytes(int M, int N, int K);
 size_t gtg_gemm_rows_workspace_bytes(void);
 int gtg_gemm_f32_rows(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
                       int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, const int32_t* rows_dev,
-                      void* ws, size_t ws_bytes, void* stream);
+                      int matrix_mode, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -79,8 +79,9 @@ def test_joint_forward_matches_composition_of_reference_pieces():
     assert abs(acc - text_acc) < 1e-6
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("name,B,N,d,hid", [("A", 64, 10, 32, 512), ("B", 256, 32, 256, 512)])
-def test_named_config_training_step_matches_oracle(name, B, N, d, hid):
+def test_named_config_training_step_matches_oracle(name, B, N, d, hid, mode):
     """Reference defaults (A) and the mid-size configuration (B): losses, every gradient and the
     parameters after one Adam step, against the oracle on the same weights, batch and eps."""
     from gtg_vae_amd.data import synth_graph_batch
@@ -88,7 +89,7 @@ def test_named_config_training_step_matches_oracle(name, B, N, d, hid):
     from oracle import graphvae_oracle as O
 
     params = O.init_params(N, d, hid, N, seed=0)
-    tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params)
+    tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params, matrix_mode=mode)
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     batch = synth_graph_batch(B, N, seed=1234)
     eps = torch.randn(B, d, generator=torch.Generator().manual_seed(9))
@@ -162,3 +163,30 @@ def test_random_awkward_shapes_match_oracle(case):
         for k in p:
             if p[k].grad.abs().max() > 0:
                 assert _relerr(tr.named_grads()[k], p[k].grad) < 1e-4, (B, N, d, hid, use_graph, k)
+
+
+def test_bf16_matrix_mode_meets_the_bf16_tolerances():
+    """Plain bf16 operands in the large encoder GEMMs (config B, where they run on the 128x128 tiles): loss
+    within 1e-3 relative, every gradient at cosine similarity >= 0.999 with the fp32 oracle."""
+    from gtg_vae_amd.data import synth_graph_batch
+    from gtg_vae_amd.trainer import GraphVAETrainer
+    from oracle import graphvae_oracle as O
+
+    B, N, d, hid = 256, 32, 256, 512
+    params = O.init_params(N, d, hid, N, seed=0)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    batch = synth_graph_batch(B, N, seed=1234)
+    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(9))
+    loss, rec, kl, _ = O.graph_step_loss(p, None, batch.edge_index, batch.adj_padded, eps, 0.5, B, N)
+    loss.backward()
+    tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params, matrix_mode="bf16")
+    res = tr.step(batch.to("cuda"), eps.cuda(), kl_w=0.5, update=False)
+    assert abs(res["recon"].item() - rec.item()) <= 1e-3 * abs(rec.item())
+    assert abs(res["kl"].item() - kl.item()) <= 1e-3 * abs(kl.item()) + 1e-6
+    exact = True
+    for k in p:
+        g, w = tr.named_grads()[k].double().cpu().flatten(), p[k].grad.double().flatten()
+        cos = torch.dot(g, w) / (g.norm() * w.norm() + 1e-30)
+        assert cos.item() >= 0.999, (k, cos.item())
+        exact = exact and _relerr(tr.named_grads()[k], p[k].grad) < 1e-6
+    assert not exact        # the coarse pipe really ran

@@ -7,6 +7,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+MODE = os.environ.get("GTG_MATRIX_MODE", "f32")  # matrix pipe under test: f32 | bf16x3 | bf16
+
 from gtg_vae_amd import _lib
 from gtg_vae_amd import functional as Fn
 
@@ -32,12 +34,12 @@ for name, sa, sb, akc, bkc, epi, saux in shapes:
     out = torch.empty(M, N, device="cuda")
     bias = torch.zeros(N, device="cuda") if epi in (1, 2) else None
     for _ in range(3):
-        Fn.gemm(A, B, akc, bkc, bias=bias, epilogue=epi, aux=aux, out=out)
+        Fn.gemm(A, B, akc, bkc, bias=bias, epilogue=epi, aux=aux, out=out, matrix_mode=MODE)
     torch.cuda.synchronize()
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
     for _ in range(reps):
-        Fn.gemm(A, B, akc, bkc, bias=bias, epilogue=epi, aux=aux, out=out)
+        Fn.gemm(A, B, akc, bkc, bias=bias, epilogue=epi, aux=aux, out=out, matrix_mode=MODE)
     t1.record(); torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / reps
     print("%-26s M=%6d N=%5d K=%6d  %8.3f ms  %7.1f TFLOP/s" % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9))

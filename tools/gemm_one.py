@@ -9,6 +9,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+MODE = os.environ.get("GTG_MATRIX_MODE", "f32")  # matrix pipe under test: f32 | bf16x3 | bf16
+
 from gtg_vae_amd import functional as Fn
 
 which = sys.argv[1] if len(sys.argv) > 1 else "nt"
@@ -37,11 +39,11 @@ if which.startswith("rows_"):
         A, B, akc, bkc, epi, aux = torch.randn(M, H, device="cuda"), torch.randn(D, H, device="cuda"), True, True, 0, None
     out = torch.empty((M, B.shape[0] if bkc else B.shape[1]), device="cuda")
     for _ in range(reps):
-        Fn.gemm_rows(A, B, akc, bkc, rows_dev=rd, epilogue=epi, aux=aux, out=out)
+        Fn.gemm_rows(A, B, akc, bkc, rows_dev=rd, epilogue=epi, aux=aux, out=out, matrix_mode=MODE)
     torch.cuda.synchronize()
     print("done", which, out.shape)
     sys.exit(0)
 for _ in range(reps):
-    out = Fn.gemm(A, B, akc, bkc, epilogue=epi, aux=aux)
+    out = Fn.gemm(A, B, akc, bkc, epilogue=epi, aux=aux, matrix_mode=MODE)
 torch.cuda.synchronize()
 print("done", which, out.shape)

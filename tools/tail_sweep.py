@@ -7,6 +7,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+MODE = os.environ.get("GTG_MATRIX_MODE", "f32")  # matrix pipe under test: f32 | bf16x3 | bf16
+
 from gtg_vae_amd import functional as Fn
 
 which = sys.argv[1] if len(sys.argv) > 1 else "nt"
@@ -30,12 +32,12 @@ for tiles in [256, 384, 512, 520, 576, 640, 652, 704, 768, 896, 1024, 1100, 1304
         break
     rd = torch.tensor([rows], dtype=torch.int32, device="cuda")
     for _ in range(3):
-        Fn.gemm_rows(A, B, True, bkc, rows_dev=rd, out=out)
+        Fn.gemm_rows(A, B, True, bkc, rows_dev=rd, out=out, matrix_mode=MODE)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20
     e0.record()
     for _ in range(reps):
-        Fn.gemm_rows(A, B, True, bkc, rows_dev=rd, out=out)
+        Fn.gemm_rows(A, B, True, bkc, rows_dev=rd, out=out, matrix_mode=MODE)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
