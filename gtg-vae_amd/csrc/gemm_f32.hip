@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
         // run a copy of the loop without a single guard or branch in the step, so that the compiler can count
         // the outstanding loads instead of draining them and can place the split arithmetic between the MFMAs.
         constexpr int PL = PREC;
-        constexpr int DEPTH = 3;
+        constexpr int DEPTH = 3;  // deeper rings (4, 5) measured no faster
         f32x4 ra[DEPTH][TA::NV], rb[DEPTH][TB::NV];
         const bool fast = m0 + BM <= Mr && n0 + BN <= a.N && (k_end - k_begin) % KS == 0 && nk > 0 &&
                           (!AKC || a.vecA) && (!BKC || a.vecB);
@@ -598,9 +598,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
                 if (kt0 < nk) step(fast_tag, kt0, std::integral_constant<int, 1 % DEPTH>());
                 if (kt0 + 1 < nk) step(fast_tag, kt0 + 1, std::integral_constant<int, 2 % DEPTH>());
                 if (kt0 + 2 < nk) step(fast_tag, kt0 + 2, std::integral_constant<int, 3 % DEPTH>());
+                if constexpr (DEPTH > 3)
+                    if (kt0 + 3 < nk) step(fast_tag, kt0 + 3, std::integral_constant<int, 4 % DEPTH>());
+                if constexpr (DEPTH > 4)
+                    if (kt0 + 4 < nk) step(fast_tag, kt0 + 4, std::integral_constant<int, 5 % DEPTH>());
+                if constexpr (DEPTH > 5)
+                    if (kt0 + 5 < nk) step(fast_tag, kt0 + 5, std::integral_constant<int, 6 % DEPTH>());
             }
         };
-        static_assert(DEPTH == 3, "the step calls above are written out for a ring of three");
+        static_assert(DEPTH >= 3 && DEPTH <= 6, "the step calls above are written out for rings of three to six");
         if (fast)
             run(std::true_type());
         else
