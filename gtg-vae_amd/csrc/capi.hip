@@ -432,8 +432,7 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float
     const int32_t* real_rows = meta + 2 * B;      // R
     const int32_t* all_rows = meta + 2 * B + 1;   // R + n
 
-    GTG_TRY(clear_i32(w.tail_cnt, (int64_t)w.tail_cnt_count, s));
-    GTG_TRY(graph_meta(counts, adj, B, n, meta, adjc, s));
+    GTG_TRY(graph_meta(counts, adj, B, n, meta, adjc, w.tail_cnt, (int)w.tail_cnt_count, s));
     GemmDesc g;
     // H1c = relu(adjc * W1^T + b1) over the R + n stored rows: a graph's compact adjacency rows are zero past
     // its n_b columns, so one plain GEMM with K = n serves every graph, and the unit rows appended to adjc
@@ -512,9 +511,8 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_encoder_compact_bwd: workspace too small");
     const int32_t* all_rows = meta + 2 * B + 1;  // R + n
 
-    GTG_TRY(clear_i32(w.tail_cnt, (int64_t)w.tail_cnt_count, s));
     // dT2c: real rows from the max-pool routing, prototype rows from the graphs whose maximum they won
-    GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, s));
+    GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, w.tail_cnt, (int)w.tail_cnt_count, s));
     GTG_TRY(proto_grad(dpooled, argmax, meta, B, n, d, w.pg, w.dT2c, s));
     GTG_TRY(colsum(dpooled, B, d, d, w.cs, db2, s));
     GemmDesc g;
@@ -763,6 +761,20 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
     g.B = D1; g.ldb = d; g.b_kc = false;
     g.C = dz; g.ldc = d; g.M = B; g.N = d; g.K = hid;
     return gemm(g, s);
+}
+
+// ---------------------------------------------------------------------------
+// batch staging (one launch instead of four device-to-device copies)
+// ---------------------------------------------------------------------------
+int gtg_stage_batch(const int64_t* edge_index, int64_t num_edges, int64_t* edge_buf, int64_t edge_capacity,
+                    const float* adj_target, float* target_buf, int64_t target_count, const float* eps,
+                    float* eps_buf, int64_t eps_count, void* stream)
+{
+    GTG_REQUIRE(num_edges >= 0 && edge_capacity >= num_edges && target_count >= 0 && eps_count >= 0, "bad size");
+    GTG_REQUIRE((edge_capacity == 0 || edge_buf) && (num_edges == 0 || edge_index), "null edge pointer");
+    GTG_REQUIRE((target_count == 0 || (adj_target && target_buf)) && (eps_count == 0 || (eps && eps_buf)), "null pointer");
+    return stage_batch(edge_index, num_edges, edge_buf, edge_capacity, adj_target, target_buf, target_count, eps, eps_buf,
+                       eps_count, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

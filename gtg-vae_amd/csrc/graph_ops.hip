@@ -68,6 +68,41 @@ __global__ __launch_bounds__(256) void adj_count_kernel(const int64_t* __restric
     atomicAdd(&counts[g * n * n + (t % n) * n + (s % n)], 1);
 }
 
+// One launch that brings a batch into the step's static buffers: the (2, E) edge list into a (2, E_cap) buffer
+// whose tail is filled with (0, 0) self loops (dropped by adj_count_kernel), the padded targets and eps.
+// Work item = one int64 of the edge buffer, or one 16-byte piece (or scalar tail) of the float buffers.
+__global__ __launch_bounds__(256) void stage_batch_kernel(const int64_t* __restrict__ ei_src, int64_t E,
+                                                          int64_t* __restrict__ ei_dst, int64_t E_cap,
+                                                          const float* __restrict__ a_src, float* __restrict__ a_dst,
+                                                          int64_t a_count, const float* __restrict__ e_src,
+                                                          float* __restrict__ e_dst, int64_t e_count, int vec)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * E_cap) {
+        const int64_t row = i / E_cap, e = i - row * E_cap;
+        ei_dst[i] = e < E ? ei_src[row * E + e] : 0;
+        return;
+    }
+    i -= 2 * E_cap;
+    const int64_t a_items = (a_count + 3) / 4, e_items = (e_count + 3) / 4;
+    const float* src;
+    float* dst;
+    int64_t count;
+    if (i < a_items) {
+        src = a_src; dst = a_dst; count = a_count;
+    } else if (i - a_items < e_items) {
+        i -= a_items;
+        src = e_src; dst = e_dst; count = e_count;
+    } else {
+        return;
+    }
+    if (vec && 4 * i + 3 < count) {
+        *reinterpret_cast<f32x4*>(dst + 4 * i) = *reinterpret_cast<const f32x4*>(src + 4 * i);
+    } else {
+        for (int64_t j = 4 * i; j < count && j < 4 * i + 4; ++j) dst[j] = src[j];
+    }
+}
+
 __global__ __launch_bounds__(256) void clear_i32_kernel(int32_t* __restrict__ p, int64_t count)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,11 +306,15 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
 // n extra nodes whose adjacency row is the unit vector, so every row-wise GEMM and
 // reduction of forward and backward covers them with no special case)
 // ---------------------------------------------------------------------------
+// (also clears `zero_count` int32 words at `zero`, the arrival counters of the GEMMs that follow: one
+// launch less than a separate clear)
 __global__ __launch_bounds__(64) void graph_extent_kernel(const int32_t* __restrict__ counts, int n,
-                                                          int32_t* __restrict__ n_real)
+                                                          int32_t* __restrict__ n_real, int32_t* __restrict__ zero,
+                                                          int zero_count)
 {
     const int64_t b = blockIdx.x;
     const int lane = threadIdx.x;
+    for (int i = blockIdx.x * 64 + lane; i < zero_count; i += gridDim.x * 64) zero[i] = 0;
     const int32_t* c = counts + b * n * n;
     int touched = 0;
     if (lane < n)
@@ -363,12 +402,16 @@ __global__ __launch_bounds__(256) void pool_bwd_gather_compact_kernel(const floa
                                                                       const float* __restrict__ dpool,
                                                                       const int32_t* __restrict__ argmax,
                                                                       const int32_t* __restrict__ meta, int64_t B,
-                                                                      int n, int d, float* __restrict__ dT2)
+                                                                      int n, int d, float* __restrict__ dT2,
+                                                                      int32_t* __restrict__ zero, int zero_count)
 {
     // the graph's adjacency block sits in LDS, one padded row per winning-row lookup
     __shared__ float sadj[64 * 65];
     const int64_t b = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // also clears the arrival counters of the GEMM that follows (one launch less than a separate clear)
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_count; i += gridDim.x * gridDim.y * 256)
+        zero[i] = 0;
     const int nb = meta[b], off = meta[B + b];
     const float* src = adj + b * n * n;
     for (int idx = threadIdx.x; idx < nb * n; idx += 256) sadj[(idx / n) * 65 + (idx % n)] = src[idx];
@@ -548,6 +591,18 @@ int adj_count(const int64_t* ei, int64_t E, int64_t B, int n, int32_t* counts, i
     return check_launch("adj_count_kernel");
 }
 
+int stage_batch(const int64_t* ei_src, int64_t E, int64_t* ei_dst, int64_t E_cap, const float* a_src, float* a_dst,
+                int64_t a_count, const float* e_src, float* e_dst, int64_t e_count, hipStream_t s)
+{
+    const int64_t items = 2 * E_cap + (a_count + 3) / 4 + (e_count + 3) / 4;
+    if (items == 0) return GTG_OK;
+    const int vec = ((reinterpret_cast<uintptr_t>(a_src) | reinterpret_cast<uintptr_t>(a_dst) |
+                      reinterpret_cast<uintptr_t>(e_src) | reinterpret_cast<uintptr_t>(e_dst)) & 15) == 0;
+    hipLaunchKernelGGL(stage_batch_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, ei_src, E, ei_dst,
+                       E_cap, a_src, a_dst, a_count, e_src, e_dst, e_count, vec);
+    return check_launch("stage_batch_kernel");
+}
+
 int clear_i32(int32_t* p, int64_t count, hipStream_t s)
 {
     if (count <= 0) return GTG_OK;
@@ -657,10 +712,11 @@ int bce_bwd(const float* out, const float* adj, int64_t B, int n, const float* g
     return check_launch("bce_bwd_kernel");
 }
 
-int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, hipStream_t s)
+int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, int32_t* zero,
+               int zero_count, hipStream_t s)
 {
-    if (B == 0) return GTG_OK;
-    hipLaunchKernelGGL(graph_extent_kernel, dim3((unsigned)B), dim3(64), 0, s, counts, n, meta);
+    if (B == 0) return clear_i32(zero, zero_count, s);
+    hipLaunchKernelGGL(graph_extent_kernel, dim3((unsigned)B), dim3(64), 0, s, counts, n, meta, zero, zero_count);
     int rc = check_launch("graph_extent_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(graph_offsets_kernel, dim3(1), dim3(256), 0, s, meta, (int)B, n, meta + B);
@@ -679,11 +735,11 @@ int proto_suffix_max(const float* t2c, const int32_t* row_base, const float* b2,
 }
 
 int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,
-                            int64_t B, int n, int d, float* dT2, hipStream_t s)
+                            int64_t B, int n, int d, float* dT2, int32_t* zero, int zero_count, hipStream_t s)
 {
-    if (B == 0 || d == 0) return GTG_OK;
+    if (B == 0 || d == 0) return clear_i32(zero, zero_count, s);
     hipLaunchKernelGGL(pool_bwd_gather_compact_kernel, dim3((d + 255) / 256, (unsigned)B), dim3(256), 0, s, adj, dpool,
-                       argmax, meta, B, n, d, dT2);
+                       argmax, meta, B, n, d, dT2, zero, zero_count);
     return check_launch("pool_bwd_gather_compact_kernel");
 }
 

@@ -98,6 +98,8 @@ int gemm(const GemmDesc& d, hipStream_t s);
 
 // ---- element-wise / reduction kernels (graph_ops.hip) -----------------------
 int adj_count(const int64_t* edge_index, int64_t E, int64_t B, int n, int32_t* counts, int32_t* err, hipStream_t s);
+int stage_batch(const int64_t* ei_src, int64_t E, int64_t* ei_dst, int64_t E_cap, const float* a_src, float* a_dst,
+                int64_t a_count, const float* e_src, float* e_dst, int64_t e_count, hipStream_t s);
 int clear_i32(int32_t* p, int64_t count, hipStream_t s);  // a kernel, not a memset: replays correctly in HIP graphs
 int adj_normalize(const int32_t* counts, int64_t B, int n, float* adj, hipStream_t s);
 int pool_bwd_gather(const float* adj, const float* dpool, const int32_t* argmax, int64_t B, int n, int d,
@@ -109,11 +111,13 @@ int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int 
                hipStream_t s);
 // compact node rows (identity features): meta = [n_b (B) | row offsets (B+1) | R + n], adjc = compact adjacency
 // rows followed by n identity rows (the prototype rows)
-int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, hipStream_t s);
+// zero / zero_count: int32 words cleared by the same launches (the tail-split arrival counters)
+int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, int32_t* zero,
+               int zero_count, hipStream_t s);
 int proto_suffix_max(const float* t2c, const int32_t* row_base, const float* b2, int n, int d, float* sval,
                      int32_t* sidx, hipStream_t s);
 int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,
-                            int64_t B, int n, int d, float* dT2, hipStream_t s);
+                            int64_t B, int n, int d, float* dT2, int32_t* zero, int zero_count, hipStream_t s);
 size_t proto_grad_workspace(int n, int d);
 int proto_grad(const float* dpool, const int32_t* argmax, const int32_t* meta, int64_t B, int n, int d, float* partial,
                float* dT2c, hipStream_t s);

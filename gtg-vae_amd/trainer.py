@@ -166,11 +166,19 @@ class GraphVAETrainer:
         drops, so the launch shapes do not depend on the number of edges."""
         B, E = batch.num_graphs, batch.edge_index.shape[1]
         self._ensure_capacity(B, E)
-        self.ei[:, :E].copy_(batch.edge_index, non_blocking=True)
-        if E < self._cap_E:
-            self.ei[:, E:].zero_()
-        self.target[:B].copy_(batch.adj_padded, non_blocking=True)
-        self.eps_buf[:B].copy_(eps, non_blocking=True)
+        ei, adj = batch.edge_index, batch.adj_padded
+        if (ei.is_cuda and adj.is_cuda and eps.is_cuda and ei.dtype == torch.int64 and ei.is_contiguous()
+                and adj.dtype == torch.float32 and adj.is_contiguous() and eps.dtype == torch.float32
+                and eps.is_contiguous()):
+            check(self.L.gtg_stage_batch(ptr(ei), E, ptr(self.ei), self._cap_E, ptr(adj), ptr(self.target), adj.numel(),
+                                         ptr(eps), ptr(self.eps_buf), eps.numel(),
+                                         torch.cuda.current_stream(self.dev).cuda_stream), "gtg_stage_batch")
+        else:  # host tensors or other dtypes: let torch convert and copy
+            self.ei[:, :E].copy_(ei, non_blocking=True)
+            if E < self._cap_E:
+                self.ei[:, E:].zero_()
+            self.target[:B].copy_(adj, non_blocking=True)
+            self.eps_buf[:B].copy_(eps, non_blocking=True)
         self._B = B
 
     # ------------------------------------------------------------------ the step

@@ -179,6 +179,16 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
                     int64_t num_graphs, int d, int hid, int m_out, float* dD1, float* dc1, float* dD2, float* dc2,
                     float* dz, void* ws, size_t ws_bytes, void* stream);
 
+/* Brings one batch into the static buffers of a graph-captured step in a single
+ * launch (the loop of train.py:297-312 hands the model a fresh batch every
+ * iteration): the (2, num_edges) int64 edge list into a (2, edge_capacity)
+ * buffer, the tail filled with (0,0) self loops that gtg_adj_build drops, so
+ * launch shapes do not depend on the edge count; the padded targets
+ * (target_count floats) and eps (eps_count floats). */
+int gtg_stage_batch(const int64_t* edge_index, int64_t num_edges, int64_t* edge_buf, int64_t edge_capacity,
+                    const float* adj_target, float* target_buf, int64_t target_count, const float* eps,
+                    float* eps_buf, int64_t eps_count, void* stream);
+
 /* ---- optimiser -------------------------------------------------------------
  * Replaces optim.Adam(lr, betas=(0.5, 0.999)).step() (src/train.py:290,314)
  * over one flat fp32 buffer.  state16: 16 device bytes, zero-initialised by the
