@@ -777,6 +777,20 @@ int gtg_stage_batch(const int64_t* edge_index, int64_t num_edges, int64_t* edge_
                        eps_count, (hipStream_t)stream);
 }
 
+int gtg_gather_batch(const int64_t* edges_local, int64_t total_edges, const int64_t* edge_start, const float* adj_all,
+                     int64_t num_dataset_graphs, int n, const int64_t* graph_ids, int64_t num_graphs, int64_t* offsets,
+                     int64_t* edge_buf, int64_t edge_capacity, float* target_buf, int32_t* err, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && num_graphs < (1 << 30) && n >= 1 && num_dataset_graphs >= 1 && total_edges >= 0 &&
+                    edge_capacity >= 0,
+                "bad size");
+    GTG_REQUIRE(edge_start && adj_all && graph_ids && offsets && target_buf && err && (total_edges == 0 || edges_local) &&
+                    (edge_capacity == 0 || edge_buf),
+                "null pointer");
+    return gather_batch(edges_local, total_edges, edge_start, adj_all, num_dataset_graphs, n, graph_ids, (int)num_graphs,
+                        offsets, edge_buf, edge_capacity, target_buf, err, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------
 // optimiser
 // ---------------------------------------------------------------------------

@@ -103,6 +103,92 @@ __global__ __launch_bounds__(256) void stage_batch_kernel(const int64_t* __restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// Batches gathered from a dataset that lives in HBM.  The dataset keeps every
+// graph's edge list with LOCAL node ids, concatenated (2, E_all) with (G+1)
+// start offsets, and the padded targets (G, n, n).  A batch is a list of B
+// graph ids: kernel 1 (one block) scans the selected graphs' edge counts into
+// B+1 output offsets; kernel 2 (one block per slot, plus blocks for the tail)
+// writes the (2, E_cap) edge buffer with ids shifted to slot * n and the tail
+// filled with (0,0) self loops, and copies the targets.  No host involvement
+// beyond the id list, so the launches depend on nothing the host must read back.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_offsets_kernel(const int64_t* __restrict__ estart,
+                                                             const int64_t* __restrict__ idx, int B, int64_t G,
+                                                             int64_t E_cap, int64_t* __restrict__ off,
+                                                             int32_t* __restrict__ err)
+{
+    __shared__ int64_t part[256];
+    const int t = threadIdx.x;
+    const int per = (B + 255) / 256;
+    const int lo = t * per, hi = min(B, lo + per);
+    int64_t s = 0;
+    bool bad = false;
+    for (int b = lo; b < hi; ++b) {
+        const int64_t g = idx[b];
+        if (g < 0 || g >= G)
+            bad = true;
+        else
+            s += estart[g + 1] - estart[g];
+    }
+    part[t] = s;
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (t == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int64_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        off[B] = run;
+        // this launch owns the word: 2 = the batch's edges do not fit the edge buffer, 4 = an id outside the dataset
+        *err = (run > E_cap ? 2 : 0) | (any_bad ? 4 : 0);
+    }
+    __syncthreads();
+    int64_t run = part[t];
+    for (int b = lo; b < hi; ++b) {
+        off[b] = run;
+        const int64_t g = idx[b];
+        if (g >= 0 && g < G) run += estart[g + 1] - estart[g];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_batch_kernel(const int64_t* __restrict__ esrc, int64_t E_all,
+                                                           const int64_t* __restrict__ estart,
+                                                           const float* __restrict__ adj_all,
+                                                           const int64_t* __restrict__ idx, int B, int64_t G, int n,
+                                                           const int64_t* __restrict__ off, int64_t* __restrict__ ei_dst,
+                                                           int64_t E_cap, float* __restrict__ target_dst)
+{
+    const int b = blockIdx.x;
+    if (b >= B) {
+        // tail of the edge buffer: (0, 0) self loops
+        const int64_t total = min(off[B], E_cap);
+        const int64_t tail_blocks = gridDim.x - B;
+        for (int64_t e = total + (int64_t)(b - B) * 256 + threadIdx.x; e < E_cap; e += tail_blocks * 256) {
+            ei_dst[e] = 0;
+            ei_dst[E_cap + e] = 0;
+        }
+        return;
+    }
+    const int64_t g = idx[b];
+    float* tdst = target_dst + (int64_t)b * n * n;
+    if (g < 0 || g >= G) {  // flagged by the offsets kernel: leave an empty graph
+        for (int i = threadIdx.x; i < n * n; i += 256) tdst[i] = 0.f;
+        return;
+    }
+    const int64_t e0 = estart[g], cnt = estart[g + 1] - e0, o = off[b];
+    const int64_t shift = (int64_t)b * n;
+    for (int64_t e = threadIdx.x; e < cnt; e += 256) {
+        if (o + e < E_cap) {
+            ei_dst[o + e] = esrc[e0 + e] + shift;
+            ei_dst[E_cap + o + e] = esrc[E_all + e0 + e] + shift;
+        }
+    }
+    const float* tsrc = adj_all + g * n * n;
+    for (int i = threadIdx.x; i < n * n; i += 256) tdst[i] = tsrc[i];
+}
+
 __global__ __launch_bounds__(256) void clear_i32_kernel(int32_t* __restrict__ p, int64_t count)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -601,6 +687,19 @@ int stage_batch(const int64_t* ei_src, int64_t E, int64_t* ei_dst, int64_t E_cap
     hipLaunchKernelGGL(stage_batch_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, ei_src, E, ei_dst,
                        E_cap, a_src, a_dst, a_count, e_src, e_dst, e_count, vec);
     return check_launch("stage_batch_kernel");
+}
+
+int gather_batch(const int64_t* esrc, int64_t E_all, const int64_t* estart, const float* adj_all, int64_t G, int n,
+                 const int64_t* idx, int B, int64_t* off, int64_t* ei_dst, int64_t E_cap, float* target_dst, int32_t* err,
+                 hipStream_t s)
+{
+    hipLaunchKernelGGL(gather_offsets_kernel, dim3(1), dim3(256), 0, s, estart, idx, B, G, E_cap, off, err);
+    int rc = check_launch("gather_offsets_kernel");
+    if (rc) return rc;
+    const int tail_blocks = (int)((E_cap + 4095) / 4096) + 1;
+    hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)(B + tail_blocks)), dim3(256), 0, s, esrc, E_all, estart,
+                       adj_all, idx, B, G, n, off, ei_dst, E_cap, target_dst);
+    return check_launch("gather_batch_kernel");
 }
 
 int clear_i32(int32_t* p, int64_t count, hipStream_t s)

@@ -100,6 +100,9 @@ int gemm(const GemmDesc& d, hipStream_t s);
 int adj_count(const int64_t* edge_index, int64_t E, int64_t B, int n, int32_t* counts, int32_t* err, hipStream_t s);
 int stage_batch(const int64_t* ei_src, int64_t E, int64_t* ei_dst, int64_t E_cap, const float* a_src, float* a_dst,
                 int64_t a_count, const float* e_src, float* e_dst, int64_t e_count, hipStream_t s);
+int gather_batch(const int64_t* esrc, int64_t E_all, const int64_t* estart, const float* adj_all, int64_t G, int n,
+                 const int64_t* idx, int B, int64_t* off, int64_t* ei_dst, int64_t E_cap, float* target_dst, int32_t* err,
+                 hipStream_t s);
 int clear_i32(int32_t* p, int64_t count, hipStream_t s);  // a kernel, not a memset: replays correctly in HIP graphs
 int adj_normalize(const int32_t* counts, int64_t B, int n, float* adj, hipStream_t s);
 int pool_bwd_gather(const float* adj, const float* dpool, const int32_t* argmax, int64_t B, int n, int d,

@@ -28,6 +28,18 @@ class GraphData:
     def x(self) -> torch.Tensor:
         return torch.eye(self.maxnode, dtype=torch.float)
 
+    def adj32(self) -> torch.Tensor:
+        """adj_padded as a float32 tensor (what the model consumes), converted once."""
+        if getattr(self, "_adj32", None) is None:
+            self._adj32 = torch.from_numpy(np.asarray(self.adj_padded, dtype=np.float32))
+        return self._adj32
+
+    def gold_row(self) -> torch.Tensor:
+        """(maxnode,) int64 bit masks of the gold edges, built once."""
+        if getattr(self, "_gold_row", None) is None:
+            self._gold_row = gold_bitmask([self.gold_edges], self.maxnode)[0]
+        return self._gold_row
+
 
 def prep_graph(graph: dict, maxnode: int) -> Optional[GraphData]:
     """train.py:177-211 for one MRP graph dict; None when the graph is skipped."""
@@ -99,6 +111,16 @@ class GraphBatch:
         return GraphBatch(mv(self.edge_index), mv(self.batch), mv(self.adj_padded), self.gold_edges, self.snts,
                           self.num_graphs, self.nmax, mv(self.num_nodes), mv(self.x), mv(self.gold_bits))
 
+    def pin_memory(self) -> "GraphBatch":
+        """Host tensors in page-locked memory, so that ``to(device)`` is an asynchronous DMA."""
+        pin = lambda t: None if t is None else (t if t.is_cuda or t.is_pinned() else t.pin_memory())
+        return GraphBatch(pin(self.edge_index), pin(self.batch), pin(self.adj_padded), self.gold_edges, self.snts,
+                          self.num_graphs, self.nmax, pin(self.num_nodes), pin(self.x), pin(self.gold_bits))
+
+    def tensors(self):
+        return [t for t in (self.edge_index, self.batch, self.adj_padded, self.num_nodes, self.x, self.gold_bits)
+                if t is not None]
+
     def __len__(self):
         return self.num_graphs
 
@@ -117,11 +139,11 @@ def collate(data_list: Sequence[GraphData], nmax: int) -> GraphBatch:
     eis = [d.edge_index + g * nmax for g, d in enumerate(data_list)]
     ei = torch.cat(eis, dim=1) if eis else torch.zeros((2, 0), dtype=torch.long)
     batch = torch.arange(B, dtype=torch.long).repeat_interleave(nmax)
-    adj = torch.from_numpy(np.stack([d.adj_padded for d in data_list])).float() if B else torch.zeros((0, nmax, nmax))
+    adj = torch.stack([d.adj32() for d in data_list]) if B else torch.zeros((0, nmax, nmax))
     gold = [d.gold_edges for d in data_list]
     nn = torch.tensor([d.num_nodes for d in data_list], dtype=torch.int32)
-    return GraphBatch(ei.contiguous(), batch, adj, gold, [d.snts for d in data_list], B, nmax, nn, None,
-                      gold_bitmask(gold, nmax))
+    bits = torch.stack([d.gold_row() for d in data_list]) if B else torch.zeros((0, nmax), dtype=torch.int64)
+    return GraphBatch(ei.contiguous(), batch, adj, gold, [d.snts for d in data_list], B, nmax, nn, None, bits)
 
 
 class DataLoader:
@@ -143,6 +165,130 @@ class DataLoader:
             self._rng.shuffle(order)
         for i in range(0, len(order), self.batch_size):
             yield collate([self.dataset[j] for j in order[i:i + self.batch_size]], self.nmax)
+
+
+class DeviceDataset:
+    """The whole dataset in HBM (an AMR corpus of 60 k graphs at N = 64 is about 1 GB of targets; the card has
+    288 GB): every graph's edge list with local node ids, concatenated, with start offsets; the padded
+    targets; the gold-edge bit masks.  A batch is then a list of graph ids, gathered on the device by
+    ``GraphVAETrainer.load_indices`` -- no per-batch collate, pinning or PCIe copy."""
+
+    def __init__(self, data_list: Sequence[GraphData], nmax: int, device="cuda"):
+        self.nmax, self.num_graphs = nmax, len(data_list)
+        dev = torch.device(device)
+        lens = [d.edge_index.shape[1] for d in data_list]
+        start = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=start[1:])
+        ei = torch.cat([d.edge_index for d in data_list], dim=1) if data_list else torch.zeros((2, 0), dtype=torch.long)
+        self.max_edges_per_graph = max(lens) if lens else 0
+        self.total_edges = int(start[-1])
+        self.edges_local = ei.contiguous().to(dev)
+        self.edge_start = torch.from_numpy(start).to(dev)
+        self.adj_all = torch.from_numpy(np.stack([d.adj_padded for d in data_list]).astype(np.float32)).to(dev)
+        self.gold_bits = gold_bitmask([d.gold_edges for d in data_list], nmax).to(dev)
+        self.gold_edges = [d.gold_edges for d in data_list]
+
+    def __len__(self):
+        return self.num_graphs
+
+    def batches(self, batch_size: int, shuffle: bool = False, generator: torch.Generator = None):
+        """Device tensors of graph ids, one per batch (sequential like the reference's loader, or a permutation)."""
+        dev = self.adj_all.device
+        order = torch.randperm(self.num_graphs, generator=generator).to(dev) if shuffle else \
+            torch.arange(self.num_graphs, device=dev)
+        for i in range(0, self.num_graphs, batch_size):
+            yield order[i:i + batch_size]
+
+
+class DeviceLoader:
+    """Iterates a DeviceDataset as batches of graph ids (device int64 tensors); ``rank``/``world`` take this
+    rank's contiguous share of every batch.  ``GraphVAETrainer.load_indices`` consumes the ids."""
+
+    def __init__(self, dataset: "DeviceDataset", batch_size: int, shuffle: bool = False, seed: int = 0, rank: int = 0,
+                 world: int = 1):
+        self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+        self.rank, self.world = rank, world
+        self.sharded = True
+        self._gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for ids in self.dataset.batches(self.batch_size, self.shuffle, self._gen):
+            if self.world > 1:
+                base, rem = divmod(len(ids), self.world)
+                lo = self.rank * base + min(self.rank, rem)
+                ids = ids[lo:lo + base + (1 if self.rank < rem else 0)]
+            yield ids
+
+
+class DevicePrefetcher:
+    """Iterates a loader of host GraphBatch objects and yields them on the GPU,
+    ``depth`` batches ahead: a worker thread collates (the loader's own work),
+    pins and starts the host-to-device copies on a side stream while the step
+    of the previous batch runs; the consumer's stream only waits for the copy
+    event of the batch it is handed.  The batches are the loader's, in order."""
+
+    def __init__(self, loader, device, depth: int = 2):
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.loader, self.device, self.depth = loader, dev, max(1, depth)
+        self.dataset = getattr(loader, "dataset", None)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        import queue
+        import threading
+
+        q: "queue.Queue" = queue.Queue(self.depth)
+        copy_stream = torch.cuda.Stream(device=self.device)
+        stop = threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def worker():
+            try:
+                torch.cuda.set_device(self.device)
+                for host in self.loader:
+                    pinned = host.pin_memory()
+                    with torch.cuda.stream(copy_stream):
+                        dev = pinned.to(self.device)
+                        done = torch.cuda.Event()
+                        done.record(copy_stream)
+                    if not put((dev, done, pinned)):   # the pinned source stays alive until the copy is consumed
+                        return
+                put(None)
+            except BaseException as e:  # surfaces in the consumer
+                put(e)
+
+        t = threading.Thread(target=worker, daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                dev, done, _pinned = item
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(done)
+                for ten in dev.tensors():
+                    ten.record_stream(cur)   # allocated under the copy stream, used on this one
+                yield dev
+        finally:
+            stop.set()
 
 
 # ---------------------------------------------------------------------------

@@ -60,12 +60,17 @@ def train(train_loader, dev_loader, trainer: GraphVAETrainer, epochs, model_name
         n_inst = 0
         t0 = time.perf_counter()
         for batch in train_loader:
-            if world > 1:
+            if world > 1 and not getattr(train_loader, "sharded", False):
                 lo, hi = shard_range(batch.num_graphs, rank, world)
                 batch = slice_batch(batch, lo, hi)
-            B = batch.num_graphs
-            eps = torch.randn(B, trainer.d, generator=generator).to(trainer.dev)
-            trainer.load_batch(batch.to(trainer.dev), eps)
+            if isinstance(batch, torch.Tensor):   # graph ids of a dataset resident on the device
+                B = int(batch.numel())
+                eps = torch.randn(B, trainer.d, generator=generator).to(trainer.dev)
+                trainer.load_indices(train_loader.dataset, batch, eps)
+            else:
+                B = batch.num_graphs
+                eps = torch.randn(B, trainer.d, generator=generator).to(trainer.dev)
+                trainer.load_batch(batch if batch.edge_index.is_cuda else batch.to(trainer.dev), eps)
             res = trainer.run_loaded(update=True, use_graph=use_graph)
             # device-side accumulation: no host sync inside the epoch (the reference syncs with loss.item(), train.py:316)
             sums += torch.stack([res["recon"] + kl_anneal_w * res["kl"], res["recon"], res["kl"]]).double() * B
@@ -95,6 +100,23 @@ def train(train_loader, dev_loader, trainer: GraphVAETrainer, epochs, model_name
     return history
 
 
+class ShardedLoader:
+    """This rank's contiguous share of every batch of ``loader`` (host side, before any copy)."""
+    sharded = True
+
+    def __init__(self, loader, rank, world):
+        self.loader, self.rank, self.world = loader, rank, world
+        self.dataset = getattr(loader, "dataset", None)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            lo, hi = shard_range(batch.num_graphs, self.rank, self.world)
+            yield slice_batch(batch, lo, hi)
+
+
 def slice_batch(batch, lo, hi):
     """Graphs [lo, hi) of a collated batch (host tensors), renumbered from 0."""
     from .data import GraphBatch
@@ -122,6 +144,10 @@ def main(argv=None):
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--hip-graph", action="store_true")
+    ap.add_argument("--prefetch", type=int, default=2, help="batches collated and copied to the GPU ahead (0 = inline)")
+    ap.add_argument("--host-loader", action="store_true",
+                    help="collate every batch on the host (as the reference does) instead of keeping the training "
+                         "set in GPU memory and gathering batches there")
     ap.add_argument("--save-every", type=int, default=0)
     args = ap.parse_args(argv)
 
@@ -135,8 +161,21 @@ def main(argv=None):
         n = args.synthetic or 4096
         trn = synth_graph_list(n, args.nodes, seed=1234)
         val = synth_graph_list(max(n // 8, args.batch), args.nodes, seed=4321)
-    trn_loader = DataLoader(trn, args.batch * world, args.nodes)
     val_loader = DataLoader(val, args.batch, args.nodes) if val else None
+    if not args.host_loader:
+        from .data import DeviceDataset, DeviceLoader
+
+        trn_loader = DeviceLoader(DeviceDataset(trn, args.nodes, dev_), args.batch * world, rank=rank, world=world)
+    else:
+        trn_loader = DataLoader(trn, args.batch * world, args.nodes)
+        if world > 1:
+            trn_loader = ShardedLoader(trn_loader, rank, world)
+    if args.host_loader and args.prefetch > 0:
+        from .data import DevicePrefetcher
+
+        sharded = getattr(trn_loader, "sharded", False)
+        trn_loader = DevicePrefetcher(trn_loader, dev_, args.prefetch)
+        trn_loader.sharded = sharded
     trainer = GraphVAETrainer(args.nodes, args.latent, args.hid, args.nodes, device=dev_, lr=args.lr, seed=args.seed,
                               max_batch=args.batch, max_edges=args.batch * args.nodes * 6)
     gen = torch.Generator().manual_seed(args.seed + rank)

@@ -137,6 +137,8 @@ class GraphVAETrainer:
         self.ei = torch.zeros((2, E), dtype=torch.int64, device=dev)
         self.counts = torch.empty(B * n * n, dtype=torch.int32, device=dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.gather_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.gather_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
         self.adj = torch.empty((B, n, n), **f32)
         self.target = torch.empty((B, n, n), **f32)
         self.eps_buf = torch.empty((B, d), **f32)
@@ -179,6 +181,22 @@ class GraphVAETrainer:
                 self.ei[:, E:].zero_()
             self.target[:B].copy_(adj, non_blocking=True)
             self.eps_buf[:B].copy_(eps, non_blocking=True)
+        self._B = B
+
+    def load_indices(self, dataset, graph_ids: torch.Tensor, eps: torch.Tensor):
+        """Assemble the batch of ``graph_ids`` (int64, on the device) from a ``data.DeviceDataset`` straight into
+        the step's static buffers: two kernel launches, nothing read back."""
+        B = int(graph_ids.numel())
+        self._ensure_capacity(B, B * max(dataset.max_edges_per_graph, 1))
+        if dataset.nmax != self.n:
+            raise _lib.GtgError("dataset nmax %d != trainer nmax %d" % (dataset.nmax, self.n))
+        ids = graph_ids if (graph_ids.dtype == torch.int64 and graph_ids.is_contiguous()) else graph_ids.long().contiguous()
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        check(self.L.gtg_gather_batch(ptr(dataset.edges_local), dataset.total_edges, ptr(dataset.edge_start),
+                                      ptr(dataset.adj_all), dataset.num_graphs, self.n, ptr(ids), B, ptr(self.gather_off),
+                                      ptr(self.ei), self._cap_E, ptr(self.target), ptr(self.gather_err), stream),
+              "gtg_gather_batch")
+        self.eps_buf[:B].copy_(eps, non_blocking=True)
         self._B = B
 
     # ------------------------------------------------------------------ the step
@@ -340,5 +358,5 @@ class GraphVAETrainer:
         return res
 
     def edges_ok(self) -> bool:
-        """Host read-back of the adjacency kernel's error flag (a sync)."""
-        return int(self.err.item()) == 0
+        """Host read-back of the adjacency and batch-gather kernels' error flags (a sync)."""
+        return int(self.err.item()) == 0 and int(self.gather_err.item()) == 0

@@ -189,6 +189,21 @@ int gtg_stage_batch(const int64_t* edge_index, int64_t num_edges, int64_t* edge_
                     const float* adj_target, float* target_buf, int64_t target_count, const float* eps,
                     float* eps_buf, int64_t eps_count, void* stream);
 
+/* Batch assembly from a dataset resident in device memory (what the collate of
+ * torch_geometric's DataLoader, train.py:549, does on the host for every
+ * batch): the dataset holds every graph's edge list with local node ids,
+ * concatenated as (2, total_edges) with num_dataset_graphs + 1 start offsets,
+ * and the padded targets (num_dataset_graphs, n, n).  For the num_graphs ids in
+ * graph_ids this writes the (2, edge_capacity) edge buffer (node id = slot * n +
+ * local id, tail filled with (0,0) self loops) and the targets of the batch.
+ * offsets: num_graphs + 1 int64 of scratch.  err (one int32, written by every
+ * call): 0, or 2 when the batch's edges exceed edge_capacity (the excess is
+ * dropped), or-ed with 4 when an id is outside the dataset (that slot becomes
+ * an empty graph). */
+int gtg_gather_batch(const int64_t* edges_local, int64_t total_edges, const int64_t* edge_start, const float* adj_all,
+                     int64_t num_dataset_graphs, int n, const int64_t* graph_ids, int64_t num_graphs, int64_t* offsets,
+                     int64_t* edge_buf, int64_t edge_capacity, float* target_buf, int32_t* err, void* stream);
+
 /* ---- optimiser -------------------------------------------------------------
  * Replaces optim.Adam(lr, betas=(0.5, 0.999)).step() (src/train.py:290,314)
  * over one flat fp32 buffer.  state16: 16 device bytes, zero-initialised by the
