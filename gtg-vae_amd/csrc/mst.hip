@@ -21,6 +21,7 @@
 // symmetric n x n matrix is never materialised.  Full n x n input is staged
 // transposed (padded row stride) so that lane j reads T[j][m] conflict-free.
 #include "gtg_internal.h"
+#include "mst_fill_n64.inc"
 
 namespace gtg {
 
@@ -43,10 +44,10 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 // step is the 2 wait states a DPP read needs after a VALU write of its source.
 __device__ __forceinline__ float wave_max_uniform(float v)
 {
-    float mx;
+    float mx, t;  // t: its own register, so the caller's value needs no copy before the chain
     asm volatile(
         "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
@@ -60,8 +61,18 @@ __device__ __forceinline__ float wave_max_uniform(float v)
         "s_nop 1\n\t"
         "v_readlane_b32 %1, %0, 63\n\t"
         "s_nop 3"   // the compiler cannot see that a VALU instruction wrote this SGPR: pad its hazards here
-        : "+v"(v), "=s"(mx));
+        : "=&v"(t), "=s"(mx) : "v"(v));
     return mx;
+}
+
+// w with lane `lane` (wave-uniform) replaced by a quiet NaN: one v_writelane
+// instead of a compare and a select.  This compiler has no builtin for the
+// instruction, so the LLVM intrinsic is bound by name; going through the
+// compiler (not inline asm) keeps its hazard padding automatic.
+extern "C" __device__ int gtg_llvm_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ float mark_lane_nan(float w, int lane)
+{
+    return __int_as_float(gtg_llvm_writelane(0x7fc00000, lane, __float_as_int(w)));
 }
 
 // Asynchronous global -> LDS copy of one upper-triangular row (m_tri floats)
@@ -144,29 +155,48 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
         // cj likewise for j: the wrong candidate always lies past the right one
         // because every row of the triangle is longer than the distance walked
         // back into it.  So one add, one min and one read per element, no
-        // compare masks.  The two lane constants are laundered through an empty
+        // compare masks (n = 64 has a cheaper form still: mst_fill_n64.inc).  The two lane constants are laundered through an empty
         // asm so that the 64 addresses are not hoisted out of the graph loop
         // (they would cost 64 registers).
         typedef __attribute__((address_space(3))) const float* lds_cptr;
         int pj4 = (int)(uintptr_t)(__attribute__((address_space(3))) float*)T + 4 * jc;
         int pcj4 = (int)(uintptr_t)(__attribute__((address_space(3))) float*)T + 4 * cj;
         asm volatile("" : "+v"(pj4), "+v"(pcj4));
-#pragma unroll
-        for (int c = 0; c < 64; ++c) {
-            float v;
-            if (TRIU) {
-                const int cc = c * n - (c * (c - 1)) / 2 - c;
-                const int addr = min(pj4 + 4 * (cc - c), pcj4) + 4 * c;
-                v = *(lds_cptr)(uintptr_t)addr;
-            } else {
-                v = T[c * (MAXN + 1) + jc];
+        if constexpr (TRIU && N64) {
+            // two reads under a compile-time execution mask instead of the add + min
+            unsigned long long saved_exec;
+#define GTG_MST_FILL16(BLK_, V_, O_)                                                              \
+            {                                                                                     \
+                float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;       \
+                BLK_(t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15, saved_exec, pj4, pcj4); \
+                V_[O_ + 0] = t0, V_[O_ + 1] = t1, V_[O_ + 2] = t2, V_[O_ + 3] = t3;               \
+                V_[O_ + 4] = t4, V_[O_ + 5] = t5, V_[O_ + 6] = t6, V_[O_ + 7] = t7;               \
+                V_[O_ + 8] = t8, V_[O_ + 9] = t9, V_[O_ + 10] = t10, V_[O_ + 11] = t11;           \
+                V_[O_ + 12] = t12, V_[O_ + 13] = t13, V_[O_ + 14] = t14, V_[O_ + 15] = t15;       \
             }
-            if (c < 32)
-                lo[c] = v;
-            else
-                hi[c - 32] = v;
-            // bound the reads in flight: their destinations count against the 128-register budget
-            if ((c & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+            GTG_MST_FILL16(GTG_MST_FILL_BLOCK_0, lo, 0)
+            GTG_MST_FILL16(GTG_MST_FILL_BLOCK_1, lo, 16)
+            GTG_MST_FILL16(GTG_MST_FILL_BLOCK_2, hi, 0)
+            GTG_MST_FILL16(GTG_MST_FILL_BLOCK_3, hi, 16)
+#undef GTG_MST_FILL16
+        } else {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) {
+                float v;
+                if (TRIU) {
+                    const int cc = c * n - (c * (c - 1)) / 2 - c;
+                    const int addr = min(pj4 + 4 * (cc - c), pcj4) + 4 * c;
+                    v = *(lds_cptr)(uintptr_t)addr;
+                } else {
+                    v = T[c * (MAXN + 1) + jc];
+                }
+                if (c < 32)
+                    lo[c] = v;
+                else
+                    hi[c - 32] = v;
+                // bound the reads in flight: their destinations count against the 128-register budget
+                if ((c & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+            }
         }
         const float diag = TRIU ? T[jc * n - (jc * (jc - 1)) / 2] : T[jc * (MAXN + 1) + jc];
         // every LDS read above has returned (waited for just below): the
@@ -207,7 +237,7 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
             float tl = lo[mm & 31], th = hi[mm & 31];                            \
             asm volatile("" : "+v"(tl), "+v"(th));                               \
             const float t = (mm < 32) ? tl : th;                                 \
-            w = (j == mm) ? __builtin_nanf("") : w;                              \
+            w = mark_lane_nan(w, mm);                                            \
             const bool upd = (t != 0.f) && (t > w);                              \
             w = upd ? t : w;                                                     \
             parent = upd ? mm : parent;                                          \
