@@ -856,4 +856,114 @@ int gtg_gemm_f32_rows(const float* A, const float* B, float* C, int M, int N, in
     return gemm(g, (hipStream_t)stream);
 }
 
+// ---- vocabulary projection + token cross-entropy (text decoder) ---------------
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+size_t gtg_proj_ce_fwd_workspace_bytes(int64_t rows, int k, int vocab)
+{
+    (void)rows; (void)k; (void)vocab;
+    size_t tb, cb;
+    gemm_tail_workspace(&tb, &cb);
+    return align256(tb) + align256(cb);
+}
+
+int gtg_proj_ce_fwd(const float* H, const float* W, const float* bias, const int64_t* targets, int64_t rows, int k,
+                    int vocab, int64_t padidx, float* loss, int32_t* pred, int32_t* rowmap, float* Hc, float* P,
+                    int64_t ldp, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
+    GTG_REQUIRE(rows >= 0 && k > 0 && vocab > 0, "bad size");
+    GTG_REQUIRE(rows <= (1 << 30) / 2, "too many rows");
+    if (rows == 0) return GTG_OK;
+    GTG_REQUIRE(H && W && targets && loss && pred && rowmap && Hc && P, "null pointer");
+    GTG_REQUIRE(ldp >= vocab && (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(P) & 15) == 0,
+                "P needs 16-byte alignment and a row stride that is a multiple of 4 and >= vocab");
+    GTG_REQUIRE(ws != nullptr && ws_bytes >= gtg_proj_ce_fwd_workspace_bytes(rows, k, vocab), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    size_t tb, cb;
+    gemm_tail_workspace(&tb, &cb);
+    float* tail_ws = reinterpret_cast<float*>(ws);
+    int32_t* tail_counters = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + align256(tb));
+
+    GTG_TRY(ce_rowmap(targets, rows, padidx, rowmap, loss, pred, s));
+    GTG_TRY(ce_rows(0, H, nullptr, rowmap, rows, k, Hc, s));
+    GTG_TRY(clear_i32(tail_counters, (int64_t)(cb / sizeof(int32_t)), s));
+    GemmDesc g;  // P[:count] = Hc W^T + bias
+    g.A = Hc; g.lda = k; g.a_kc = true;
+    g.B = W; g.ldb = k; g.b_kc = true;
+    g.C = P; g.ldc = (int)ldp;
+    g.M = (int)rows; g.N = vocab; g.K = k;
+    g.bias = bias;
+    g.m_dev = rowmap;
+    g.tail_ws = tail_ws; g.tail_counters = tail_counters;
+    GTG_TRY(gemm(g, s));
+    return ce_softmax(P, ldp, vocab, targets, rowmap, rows, loss, pred, s);
+}
+
+size_t gtg_proj_ce_bwd_workspace_bytes(int64_t rows, int k, int vocab)
+{
+    size_t tb, cb;
+    gemm_tail_workspace(&tb, &cb);
+    return align256(tb) + align256(cb) + 2 * align256((size_t)rows * k * sizeof(float)) +
+           align256(ce_bias_grad_workspace(vocab));
+}
+
+int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, const float* Hc, const float* P,
+                    int64_t ldp, int64_t rows, int k, int vocab, float* dH, float* dW, float* db, int matrix_mode,
+                    void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
+    GTG_REQUIRE(rows >= 0 && k > 0 && vocab > 0, "bad size");
+    GTG_REQUIRE(rows <= (1 << 30) / 2, "too many rows");
+    GTG_REQUIRE(W && dW, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows == 0) {
+        GTG_TRY(clear_i32(reinterpret_cast<int32_t*>(dW), (int64_t)vocab * k, s));
+        if (db) GTG_TRY(clear_i32(reinterpret_cast<int32_t*>(db), vocab, s));
+        return GTG_OK;
+    }
+    GTG_REQUIRE(gloss && rowmap && Hc && P, "null pointer");
+    GTG_REQUIRE(ldp >= vocab && (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(P) & 15) == 0,
+                "P needs 16-byte alignment and a row stride that is a multiple of 4 and >= vocab");
+    GTG_REQUIRE(ws != nullptr && ws_bytes >= gtg_proj_ce_bwd_workspace_bytes(rows, k, vocab), "workspace too small");
+    size_t tb, cb;
+    gemm_tail_workspace(&tb, &cb);
+    char* w = reinterpret_cast<char*>(ws);
+    float* tail_ws = reinterpret_cast<float*>(w); w += align256(tb);
+    int32_t* tail_counters = reinterpret_cast<int32_t*>(w); w += align256(cb);
+    float* Hs = reinterpret_cast<float*>(w); w += align256((size_t)rows * k * sizeof(float));
+    float* dHc = reinterpret_cast<float*>(w); w += align256((size_t)rows * k * sizeof(float));
+    float* db_partial = reinterpret_cast<float*>(w);
+    const int* count = rowmap;
+
+    // dW (vocab, k) = P^T diag(g) Hc over the kept rows (K extent on the device)
+    GTG_TRY(ce_rows(1, Hc, gloss, rowmap, rows, k, Hs, s));
+    {
+        GemmDesc g;
+        g.A = P; g.lda = (int)ldp; g.a_kc = false;
+        g.B = Hs; g.ldb = k; g.b_kc = false;
+        g.C = dW; g.ldc = k;
+        g.M = vocab; g.N = k; g.K = (int)rows;
+        g.k_dev = count;
+        GTG_TRY(gemm(g, s));
+    }
+    if (db) GTG_TRY(ce_bias_grad(P, ldp, vocab, gloss, rowmap, rows, db_partial, db, s));
+    // dH[r] = g[r] * (P W)[map[r]], pad rows zero
+    if (dH) {
+        GTG_TRY(clear_i32(tail_counters, (int64_t)(cb / sizeof(int32_t)), s));
+        GemmDesc g;
+        g.A = P; g.lda = (int)ldp; g.a_kc = true;
+        g.B = W; g.ldb = k; g.b_kc = false;
+        g.C = dHc; g.ldc = k;
+        g.M = (int)rows; g.N = k; g.K = vocab;
+        g.m_dev = count;
+        g.tail_ws = tail_ws; g.tail_counters = tail_counters;
+        GTG_TRY(gemm(g, s));
+        GTG_TRY(ce_rows(2, dHc, gloss, rowmap, rows, k, dH, s));
+    }
+    return GTG_OK;
+}
+
 }  // extern "C"

@@ -143,6 +143,20 @@ int adam_stateful(float* p, const float* g, float* m, float* v, int64_t n, void*
 int edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gold_bits, int64_t G, int n,
              float* recall, float* precision, hipStream_t s);
 
+// ---- vocabulary projection + cross-entropy (proj_ce.hip) ---------------------
+// rowmap (2 R + 1 int32): [count | compact index of row r or -1 | original row of compact row i]
+int ce_rowmap(const int64_t* targets, int64_t R, int64_t padidx, int32_t* rowmap, float* loss, int32_t* pred,
+              hipStream_t s);
+// mode 0: dst[i] = src[list[i]]; 1: dst[i] = g[list[i]] * src[i]; 2: dst[r] = map[r] >= 0 ? g[r] * src[map[r]] : 0
+int ce_rows(int mode, const float* src, const float* g, const int32_t* rowmap, int64_t R, int K, float* dst,
+            hipStream_t s);
+// in place on the compact rows of P: logits -> softmax - onehot(target); loss / pred at the original row
+int ce_softmax(float* P, int64_t ldp, int V, const int64_t* targets, const int32_t* rowmap, int64_t R, float* loss,
+               int32_t* pred, hipStream_t s);
+size_t ce_bias_grad_workspace(int V);
+int ce_bias_grad(const float* P, int64_t ldp, int V, const float* g, const int32_t* rowmap, int64_t R, float* partial,
+                 float* db, hipStream_t s);
+
 // ---- MST (mst.hip) ----------------------------------------------------------
 int mst_triu(const float* rows, int64_t G, int n, int32_t* edges, int32_t* count, hipStream_t s);
 int mst_full(const float* mats, int64_t G, int n, int32_t* edges, int32_t* count, hipStream_t s);

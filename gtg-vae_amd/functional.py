@@ -314,3 +314,62 @@ def gemm_rows(A, B, a_kc=True, b_kc=True, rows_dev=None, bias=None, epilogue=0, 
                               ptr(ws), ws.numel(), stream_ptr()),
           "gtg_gemm_f32_rows")
     return C
+
+
+# ---------------------------------------------------------------------------
+# vocabulary projection + token cross-entropy (text decoder)
+# ---------------------------------------------------------------------------
+class ProjCEFn(torch.autograd.Function):
+    """loss (rows) = cross_entropy(H W^T + b, targets, ignore_index=padidx, reduction='none'),
+    pred (rows) int32 = argmax of the logits (-1 where the target is the pad symbol).
+
+    text_vae.py:65 (self.proj) + :77-79 (loss_rec) + :83-84 (accuracy's arg-max)
+    without ever holding the logits of pad tokens: those rows are left out of
+    all three GEMMs."""
+
+    @staticmethod
+    def forward(ctx, H, W, b, targets, padidx, matrix_mode=None):
+        L = _lib.lib()
+        ctx.mode = mode = _lib.matrix_mode(matrix_mode)
+        H, W, b = map(_f32c, (H, W, b))
+        _lib.require_cuda(targets)
+        targets = targets.contiguous().long().view(-1)
+        R, K = H.shape
+        V = W.shape[0]
+        if W.shape[1] != K or targets.numel() != R or (b is not None and b.numel() != V):
+            raise _lib.GtgError("proj_ce: H (rows, k), W (vocab, k), b (vocab), targets (rows)")
+        dev = H.device
+        ldp = (V + 31) // 32 * 32
+        loss = torch.empty((R,), dtype=torch.float32, device=dev)
+        pred = torch.empty((R,), dtype=torch.int32, device=dev)
+        rowmap = torch.empty((2 * R + 1,), dtype=torch.int32, device=dev)
+        Hc = torch.empty((R, K), dtype=torch.float32, device=dev)
+        P = torch.empty((R, ldp), dtype=torch.float32, device=dev)
+        ws = _ws(L.gtg_proj_ce_fwd_workspace_bytes(R, K, V), dev)
+        check(L.gtg_proj_ce_fwd(ptr(H), ptr(W), ptr(b), ptr(targets), R, K, V, int(padidx), ptr(loss), ptr(pred),
+                                ptr(rowmap), ptr(Hc), ptr(P), ldp, mode, ptr(ws), ws.numel(), stream_ptr()),
+              "gtg_proj_ce_fwd")
+        ctx.save_for_backward(W, rowmap, Hc, P)
+        ctx.dims = (R, K, V, ldp, b is not None)
+        ctx.mark_non_differentiable(pred)
+        return loss, pred
+
+    @staticmethod
+    def backward(ctx, gloss, _gpred):
+        L = _lib.lib()
+        W, rowmap, Hc, P = ctx.saved_tensors
+        R, K, V, ldp, has_bias = ctx.dims
+        gloss = _f32c(gloss).view(-1)
+        dev = gloss.device
+        dH = torch.empty((R, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dW = torch.empty((V, K), dtype=torch.float32, device=dev)
+        db = torch.empty((V,), dtype=torch.float32, device=dev) if has_bias else None
+        ws = _ws(L.gtg_proj_ce_bwd_workspace_bytes(R, K, V), dev)
+        check(L.gtg_proj_ce_bwd(ptr(W), ptr(gloss), ptr(rowmap), ptr(Hc), ptr(P), ldp, R, K, V, ptr(dH), ptr(dW),
+                                ptr(db), ctx.mode, ptr(ws), ws.numel(), stream_ptr()), "gtg_proj_ce_bwd")
+        return dH, dW, db, None, None, None
+
+
+def proj_ce(H, W, b, targets, padidx, matrix_mode=None):
+    """Per-token cross-entropy of the projected decoder outputs and the arg-max token; see ProjCEFn."""
+    return ProjCEFn.apply(H, W, b, targets, padidx, matrix_mode)

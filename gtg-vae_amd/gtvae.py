@@ -2,7 +2,8 @@
 
 Mirrors /root/reference/src/gtvae.py:15-126.  The graph half (encode, latent
 head, reparameterisation, KL, decode, reconstruction loss) runs on the HIP
-kernels; the text half is text_vae.DAE on stock PyTorch-ROCm.
+kernels; the text half is text_vae.DAE: stock PyTorch-ROCm embeddings and LSTMs,
+HIP vocabulary projection + cross-entropy (DAE.decode_loss).
 
 Two deliberate, flag-selectable differences from the file as shipped:
 * ``text=False`` builds no text branch; joint_h is then the graph encoding
@@ -53,9 +54,9 @@ class GTVAE(nn.Module):
         text_mu = self.zg_mu(text_h)
         text_var = self.zg_var(text_h)
         text_z, text_kl_loss = Fn.ReparamKLFn.apply(text_mu, text_var, self._eps(text_mu))
-        logits, _ = self.text_vae.decode(text_z, inputs)
-        text_recon_loss = self.text_vae.loss_rec(logits, targets).mean()
-        text_acc = self.text_vae.accuracy(logits, targets, True)
+        tok_loss, pred, _ = self.text_vae.decode_loss(text_z, inputs, targets, matrix_mode=getattr(self.graph_vae, "matrix_mode", None))
+        text_recon_loss = tok_loss.sum(dim=0).mean()
+        text_acc = self.text_vae.accuracy_from_pred(pred, targets)
         return text_kl_loss + text_recon_loss, text_acc
 
     # gtvae.py:95-126
@@ -78,9 +79,10 @@ class GTVAE(nn.Module):
             self._eps(joint_h) if eps is None else eps)
         loss = joint_kl_loss * kl_anneal_w
         if self.text_vae is not None:
-            logits, _ = self.text_vae.decode(joint_z, inputs)
-            text_recon_loss = self.text_vae.loss_rec(logits, targets).mean()
-            text_acc = self.text_vae.accuracy(logits, targets, is_dev)
+            tok_loss, pred, _ = self.text_vae.decode_loss(joint_z, inputs, targets,
+                                                          matrix_mode=getattr(self.graph_vae, "matrix_mode", None))
+            text_recon_loss = tok_loss.sum(dim=0).mean()
+            text_acc = self.text_vae.accuracy_from_pred(pred, targets)
             loss = loss + text_recon_loss
         out_tensor = self.graph_vae.decode(joint_z)
         graph_recon_loss, edge_recall, edge_precision = self.graph_vae.loss(out_tensor, adj, gold_edges, report)

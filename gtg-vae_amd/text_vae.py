@@ -2,14 +2,17 @@
 
 Mirrors /root/reference/src/text_vae.py:22-132 (``TextModel``, ``DAE``): same
 sub-module names and shapes, hence the same ``state_dict`` keys
-(``embed, proj, E, G, hgen, z2emb``).  It runs on stock PyTorch-ROCm
-LSTM/GEMM kernels: the text branch sits outside the graph hot path, it is
-here so that ``GTVAE.forward`` keeps the reference's joint behaviour.
+(``embed, proj, E, G, hgen, z2emb``).  Embeddings and LSTMs run on stock
+PyTorch-ROCm kernels.  The vocabulary projection with its cross-entropy and
+arg-max -- most of the branch's arithmetic, 2*1024*vocab per token -- has a
+HIP path of its own, ``decode_loss``: it skips the pad tokens' rows in all
+three GEMMs and never holds more than one copy of the logits.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as Fn
 from .noise import noisy
 
 
@@ -49,6 +52,21 @@ class DAE(TextModel):
         output = self.drop(output)
         logits = self.proj(output.view(-1, output.size(-1)))
         return logits.view(output.size(0), output.size(1), -1), hidden
+
+    def decode_loss(self, z, input, targets, hidden=None, matrix_mode=None):
+        """decode + loss_rec + the arg-max of accuracy in one step (text_vae.py:61-66,
+        77-79, 83-84): returns (per-token loss (T, B), predicted tokens (T, B) with -1
+        at pad targets, hidden).  ``loss.sum(dim=0)`` is loss_rec's result."""
+        emb = self.drop(self.embed(input)) + self.z2emb(z)
+        output, hidden = self.G(emb, hidden)
+        output = self.drop(output)
+        loss, pred = Fn.proj_ce(output.reshape(-1, output.size(-1)), self.proj.weight, self.proj.bias,
+                                targets.reshape(-1), self.padidx, matrix_mode)
+        return loss.view(targets.size()), pred.view(targets.size()), hidden
+
+    def accuracy_from_pred(self, pred, targets):
+        mask = targets != self.padidx
+        return (((pred == targets) & mask).sum() / mask.sum()).item()
 
     def forward(self, input):
         _input = noisy(self.padidx, input, 0.3, 0, 0, 0) if self.training else input

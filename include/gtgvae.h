@@ -204,6 +204,32 @@ int gtg_gather_batch(const int64_t* edges_local, int64_t total_edges, const int6
                      int64_t num_dataset_graphs, int n, const int64_t* graph_ids, int64_t num_graphs, int64_t* offsets,
                      int64_t* edge_buf, int64_t edge_capacity, float* target_buf, int32_t* err, void* stream);
 
+/* ---- vocabulary projection + token cross-entropy (text decoder) -----------
+ * Replaces, for training, the tail of DAE.decode (src/text_vae.py:65,
+ * logits = self.proj(output)), DAE.loss_rec (src/text_vae.py:77-79,
+ * F.cross_entropy with ignore_index = pad, reduction none) and the arg-max of
+ * DAE.accuracy (src/text_vae.py:83-84) and their backward.
+ *   H (rows, k) decoder outputs (rows = T*B), W (vocab, k), bias (vocab) or
+ *   NULL, targets (rows) int64.
+ *   loss (rows): per-token cross-entropy, 0 where targets == padidx;
+ *   pred (rows) int32: arg-max of the logits (first maximum), -1 at pad rows.
+ * Rows whose target is the pad symbol take no part in any GEMM: the kept rows
+ * are packed to the front and their count stays on the device.  State handed
+ * from forward to backward (caller-allocated, opaque):
+ *   rowmap (2*rows + 1) int32, Hc (rows, k) the kept rows of H,
+ *   P (rows, ldp), ldp % 4 == 0, ldp >= vocab, 16-byte aligned: on return
+ *   softmax(logits) - onehot(target) for the kept rows.
+ * Backward takes gloss (rows), the gradient of each token's loss, and writes
+ * dH (rows, k) (may be NULL), dW (vocab, k), db (vocab) (may be NULL). */
+size_t gtg_proj_ce_fwd_workspace_bytes(int64_t rows, int k, int vocab);
+int gtg_proj_ce_fwd(const float* H, const float* W, const float* bias, const int64_t* targets, int64_t rows, int k,
+                    int vocab, int64_t padidx, float* loss, int32_t* pred, int32_t* rowmap, float* Hc, float* P,
+                    int64_t ldp, int matrix_mode, void* ws, size_t ws_bytes, void* stream);
+size_t gtg_proj_ce_bwd_workspace_bytes(int64_t rows, int k, int vocab);
+int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, const float* Hc, const float* P,
+                    int64_t ldp, int64_t rows, int k, int vocab, float* dH, float* dW, float* db, int matrix_mode,
+                    void* ws, size_t ws_bytes, void* stream);
+
 /* ---- optimiser -------------------------------------------------------------
  * Replaces optim.Adam(lr, betas=(0.5, 0.999)).step() (src/train.py:290,314)
  * over one flat fp32 buffer.  state16: 16 device bytes, zero-initialised by the
