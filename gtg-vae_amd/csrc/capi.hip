@@ -901,12 +901,22 @@ int gtg_proj_ce_fwd(const float* H, const float* W, const float* bias, const int
     return ce_softmax(P, ldp, vocab, targets, rowmap, rows, loss, pred, s);
 }
 
+// The input-gradient GEMM (kept rows x k, depth = vocab) has few output tiles and a very long K: it is
+// cut along K so that the kept rows alone (often half of all rows) still fill the chip a few times over.
+static int proj_ce_dh_splits(int64_t rows, int k)
+{
+    const long long t128 = ((rows + 127) / 128) * ((k + 127) / 128);
+    long long sp = (2048 + t128 - 1) / t128;
+    return (int)(sp < 1 ? 1 : sp > 8 ? 8 : sp);
+}
+
 size_t gtg_proj_ce_bwd_workspace_bytes(int64_t rows, int k, int vocab)
 {
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);
+    const int sp = proj_ce_dh_splits(rows, k);
     return align256(tb) + align256(cb) + 2 * align256((size_t)rows * k * sizeof(float)) +
-           align256(ce_bias_grad_workspace(vocab));
+           align256(ce_bias_grad_workspace(vocab)) + (sp > 1 ? align256((size_t)sp * rows * k * sizeof(float)) : 0);
 }
 
 int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, const float* Hc, const float* P,
@@ -935,7 +945,8 @@ int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, c
     int32_t* tail_counters = reinterpret_cast<int32_t*>(w); w += align256(cb);
     float* Hs = reinterpret_cast<float*>(w); w += align256((size_t)rows * k * sizeof(float));
     float* dHc = reinterpret_cast<float*>(w); w += align256((size_t)rows * k * sizeof(float));
-    float* db_partial = reinterpret_cast<float*>(w);
+    float* db_partial = reinterpret_cast<float*>(w); w += align256(ce_bias_grad_workspace(vocab));
+    float* dh_slabs = reinterpret_cast<float*>(w);
     const int* count = rowmap;
 
     // dW (vocab, k) = P^T diag(g) Hc over the kept rows (K extent on the device)
@@ -953,13 +964,18 @@ int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, c
     // dH[r] = g[r] * (P W)[map[r]], pad rows zero
     if (dH) {
         GTG_TRY(clear_i32(tail_counters, (int64_t)(cb / sizeof(int32_t)), s));
-        GemmDesc g;
+        GemmDesc g;  // dHc[:count] = P W
         g.A = P; g.lda = (int)ldp; g.a_kc = true;
         g.B = W; g.ldb = k; g.b_kc = false;
         g.C = dHc; g.ldc = k;
         g.M = (int)rows; g.N = k; g.K = vocab;
         g.m_dev = count;
-        g.tail_ws = tail_ws; g.tail_counters = tail_counters;
+        const int sp = proj_ce_dh_splits(rows, k);
+        if (sp > 1) {
+            g.splits = sp; g.slabs = dh_slabs;
+        } else {
+            g.tail_ws = tail_ws; g.tail_counters = tail_counters;
+        }
         GTG_TRY(gemm(g, s));
         GTG_TRY(ce_rows(2, dHc, gloss, rowmap, rows, k, dH, s));
     }

@@ -54,7 +54,7 @@ class GTVAE(nn.Module):
         text_mu = self.zg_mu(text_h)
         text_var = self.zg_var(text_h)
         text_z, text_kl_loss = Fn.ReparamKLFn.apply(text_mu, text_var, self._eps(text_mu))
-        tok_loss, pred, _ = self.text_vae.decode_loss(text_z, inputs, targets, matrix_mode=getattr(self.graph_vae, "matrix_mode", None))
+        tok_loss, pred, _ = self.text_vae.decode_loss(text_z, inputs, targets)
         text_recon_loss = tok_loss.sum(dim=0).mean()
         text_acc = self.text_vae.accuracy_from_pred(pred, targets)
         return text_kl_loss + text_recon_loss, text_acc
@@ -79,8 +79,7 @@ class GTVAE(nn.Module):
             self._eps(joint_h) if eps is None else eps)
         loss = joint_kl_loss * kl_anneal_w
         if self.text_vae is not None:
-            tok_loss, pred, _ = self.text_vae.decode_loss(joint_z, inputs, targets,
-                                                          matrix_mode=getattr(self.graph_vae, "matrix_mode", None))
+            tok_loss, pred, _ = self.text_vae.decode_loss(joint_z, inputs, targets)
             text_recon_loss = tok_loss.sum(dim=0).mean()
             text_acc = self.text_vae.accuracy_from_pred(pred, targets)
             loss = loss + text_recon_loss

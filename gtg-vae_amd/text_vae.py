@@ -56,7 +56,11 @@ class DAE(TextModel):
     def decode_loss(self, z, input, targets, hidden=None, matrix_mode=None):
         """decode + loss_rec + the arg-max of accuracy in one step (text_vae.py:61-66,
         77-79, 83-84): returns (per-token loss (T, B), predicted tokens (T, B) with -1
-        at pad targets, hidden).  ``loss.sum(dim=0)`` is loss_rec's result."""
+        at pad targets, hidden).  ``loss.sum(dim=0)`` is loss_rec's result.  The matrix
+        pipe of the three GEMMs is ``matrix_mode``, else the module's ``matrix_mode``
+        attribute if one was set, else the package default."""
+        if matrix_mode is None:
+            matrix_mode = getattr(self, "matrix_mode", None)
         emb = self.drop(self.embed(input)) + self.z2emb(z)
         output, hidden = self.G(emb, hidden)
         output = self.drop(output)
