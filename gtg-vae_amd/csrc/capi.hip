@@ -435,15 +435,20 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float
     GTG_TRY(graph_meta(counts, adj, B, n, meta, adjc, w.tail_cnt, (int)w.tail_cnt_count, s));
     GemmDesc g;
     // H1c = relu(adjc * W1^T + b1) over the R + n stored rows: a graph's compact adjacency rows are zero past
-    // its n_b columns, so one plain GEMM with K = n serves every graph, and the unit rows appended to adjc
-    // give the prototype rows relu(W1^T + b1) in the same launch
-    g.A = adjc; g.lda = n; g.a_kc = true;
-    g.B = W1; g.ldb = n; g.b_kc = true;
-    g.C = h1c; g.ldc = H;
-    g.M = rows; g.N = H; g.K = n; g.m_dev = all_rows;
-    g.bias = b1; g.epi = EPI_RELU;
-    g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
-    GTG_TRY(gemm(g, s));
+    // its n_b columns, so one product with K = n serves every graph, and the unit rows appended to adjc give
+    // the prototype rows relu(W1^T + b1) in the same launch.  A row of adjc holds deg + 1 nonzeros: the product
+    // runs as a sparse row kernel bound by the store of H1c (dense GEMM when 2d is not a multiple of 4).
+    if ((H & 3) == 0) {
+        GTG_TRY(conv1_sparse(adjc, n, W1, b1, H, all_rows, rows, h1c, s));
+    } else {
+        g.A = adjc; g.lda = n; g.a_kc = true;
+        g.B = W1; g.ldb = n; g.b_kc = true;
+        g.C = h1c; g.ldc = H;
+        g.M = rows; g.N = H; g.K = n; g.m_dev = all_rows;
+        g.bias = b1; g.epi = EPI_RELU;
+        g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
+        GTG_TRY(gemm(g, s));
+    }
     // T2c = H1c * W2^T over the R + n stored rows
     g = GemmDesc();
     g.A = h1c; g.lda = H; g.B = W2; g.ldb = H; g.C = w.t2c; g.ldc = d;

@@ -143,6 +143,11 @@ int adam_stateful(float* p, const float* g, float* m, float* v, int64_t n, void*
 int edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gold_bits, int64_t G, int n,
              float* recall, float* precision, hipStream_t s);
 
+// ---- first GCN layer on identity features as sparse row products (gcn_sparse.hip) ----
+// h1c[r] = relu(b1 + sum_k adjc[r,k] W1[:,k]) for r < min(rows_max, *rows_dev); H a multiple of 4
+int conv1_sparse(const float* adjc, int n, const float* W1, const float* b1, int H, const int* rows_dev, int rows_max,
+                 float* h1c, hipStream_t s);
+
 // ---- vocabulary projection + cross-entropy (proj_ce.hip) ---------------------
 // rowmap (2 R + 1 int32): [count | compact index of row r or -1 | original row of compact row i]
 int ce_rowmap(const int64_t* targets, int64_t R, int64_t padidx, int32_t* rowmap, float* loss, int32_t* pred,

@@ -120,6 +120,31 @@ def test_compact_encoder_edge_cases(N, d):
     assert _relerr(outs[0][0], outs[1][0]) < 1e-6
 
 
+@pytest.mark.parametrize("N,d", [(7, 6), (64, 130), (33, 5)])
+def test_compact_encoder_on_dense_graphs_and_odd_widths(N, d):
+    """First layer as sparse row products: complete graphs (every adjacency entry nonzero), a hidden
+    width 2d that is not a multiple of the 256-column slab (260) and one that is not a multiple of 4
+    (10: the dense GEMM takes over), against the oracle."""
+    from gtg_vae_amd import functional as Fn
+    from oracle import graphvae_oracle as O
+
+    B = 3
+    edges = [(b * N + i, b * N + j) for b in range(B) for i in range(N - b) for j in range(N - b) if i != j]
+    ei = torch.tensor(edges, dtype=torch.long).t().contiguous()
+    p = {k: v.clone().requires_grad_(True) for k, v in _oracle_params(N, d, 16, seed=21).items()}
+    want = O.encode(p, None, ei, B, N)
+    up = torch.randn(B, d, generator=torch.Generator().manual_seed(8))
+    (want * up).sum().backward()
+    names = ["encoder.conv1.lin.weight", "encoder.conv1.bias", "encoder.conv2.lin.weight", "encoder.conv2.bias"]
+    gp = [p[k].detach().cuda().requires_grad_(True) for k in names]
+    adj, counts = Fn.build_adj(ei.cuda(), B, N, return_counts=True)
+    got, _ = Fn.EncoderFn.apply(adj, None, *gp, counts)
+    assert _relerr(got, want) < 1e-5
+    (got * up.cuda()).sum().backward()
+    for k, t in zip(names, gp):
+        assert _relerr(t.grad, p[k].grad) < 1e-4, k
+
+
 @pytest.mark.parametrize("B,d", [(8, 32), (256, 256), (5, 7)])
 def test_latent_forward_backward(B, d):
     from gtg_vae_amd import functional as Fn
