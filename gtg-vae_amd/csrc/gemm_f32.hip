@@ -453,7 +453,67 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if constexpr (PREC == 0) {
+    if constexpr (PREC == 0 && KG > 1) {
+        // K-group configurations run batch-sized GEMMs: a block sees only a handful of k steps, each far
+        // shorter than a global load's latency, so the next FDEPTH tiles wait in registers (tile t in slot
+        // t % FDEPTH, refilled with tile t + FDEPTH as soon as it has been written to LDS): the block pays
+        // the memory latency about once instead of once per k step.
+        constexpr int FDEPTH = 4;
+        f32x4 ra[FDEPTH][TA::NV], rb[FDEPTH][TB::NV];
+#pragma unroll
+        for (int t = 0; t < FDEPTH; ++t) {
+            if (t < nk) {
+                TA::fetch(ra[t], A, a.lda, m0, Mr, k_begin + t * BK, k_end, a.vecA, tid);
+                TB::fetch(rb[t], B, a.ldb, n0, a.N, k_begin + t * BK, k_end, a.vecB, tid);
+            }
+        }
+        if (nk > 0) {
+            TA::stage(sA0, ra[0], tid);
+            TB::stage(sB0, rb[0], tid);
+            if (FDEPTH < nk) {
+                TA::fetch(ra[0], A, a.lda, m0, Mr, k_begin + FDEPTH * BK, k_end, a.vecA, tid);
+                TB::fetch(rb[0], B, a.ldb, n0, a.N, k_begin + FDEPTH * BK, k_end, a.vecB, tid);
+            }
+        }
+        __syncthreads();
+        for (int kt0 = 0; kt0 < nk; kt0 += FDEPTH) {
+#pragma unroll
+            for (int u = 0; u < FDEPTH; ++u) {
+                const int kt = kt0 + u;
+                if (kt >= nk) break;  // block-uniform
+                const int nslot = (u + 1) % FDEPTH;
+                const float* cA = (kt & 1) ? sA1 : sA0;
+                const float* cB = (kt & 1) ? sB1 : sB0;
+#pragma unroll
+                for (int g = 0; g < BK / 8; ++g) {
+                    f32x4 fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = TA::frag(cA, wm + 32 * i, g, r, h);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = TB::frag(cB, wn + 32 * j, g, r, h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                    if (g == 0) {
+                        if (kt + 1 < nk) {
+                            TA::stage((kt & 1) ? sA0 : sA1, ra[nslot], tid);
+                            TB::stage((kt & 1) ? sB0 : sB1, rb[nslot], tid);
+                        }
+                        if (kt + 1 + FDEPTH < nk) {
+                            const int k0 = k_begin + (kt + 1 + FDEPTH) * BK;
+                            TA::fetch(ra[nslot], A, a.lda, m0, Mr, k0, k_end, a.vecA, tid);
+                            TB::fetch(rb[nslot], B, a.ldb, n0, a.N, k0, k_end, a.vecB, tid);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    } else if constexpr (PREC == 0) {
         // Software pipeline: the registers ra/rb hold tile kt+1 (fetched one full
         // iteration earlier); they are written to the idle LDS buffer after the
         // first k group's MFMAs have been issued, and re-used at once for the
