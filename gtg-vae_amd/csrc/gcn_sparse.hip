@@ -21,6 +21,13 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// v where keep, +0 elsewhere, as a bit mask: written as a select the compiler moves the load that feeds
+// it back under a branch
+__device__ __forceinline__ float keep_if(float v, bool keep)
+{
+    return __int_as_float(__float_as_int(v) & -(int)keep);
+}
+
 constexpr int C1_THREADS = 512;
 constexpr int C1_COLS = 256;       // output columns per block, 4 per lane
 constexpr int C1_LD = C1_COLS + 4; // LDS row stride of the transposed weight slab (keeps 16-byte alignment)
@@ -66,16 +73,24 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_sparse_kernel(const float* _
     }
     constexpr int WAVES = C1_THREADS / 64;
     // the next group of adjacency rows is in flight while the current one is multiplied and stored
+    // (loads are unconditional, row and lane clamped into range, and zeroed afterwards: a guarded load
+    // becomes a branch with a full wait behind it)
     float a[C1_UNROLL], a_next[C1_UNROLL];
     int rb = r0 + wave * C1_UNROLL;
+    const int lane_c = min(lane, n - 1), r_last = max(r1 - 1, 0);
+    const bool lane_ok = lane < n;
 #pragma unroll
-    for (int u = 0; u < C1_UNROLL; ++u) a_next[u] = (rb + u < r1 && lane < n) ? adjc[(long long)(rb + u) * n + lane] : 0.f;
+    for (int u = 0; u < C1_UNROLL; ++u) {
+        const float t = adjc[(long long)min(rb + u, r_last) * n + lane_c];
+        a_next[u] = keep_if(t, rb + u < r1 && lane_ok);
+    }
     for (; rb < r1; rb += WAVES * C1_UNROLL) {
         const int rn = rb + WAVES * C1_UNROLL;
 #pragma unroll
         for (int u = 0; u < C1_UNROLL; ++u) {
             a[u] = a_next[u];
-            a_next[u] = (rn + u < r1 && lane < n) ? adjc[(long long)(rn + u) * n + lane] : 0.f;
+            const float t = adjc[(long long)min(rn + u, r_last) * n + lane_c];
+            a_next[u] = keep_if(t, rn + u < r1 && lane_ok);
         }
 #pragma unroll
         for (int u = 0; u < C1_UNROLL; ++u) {
