@@ -80,10 +80,11 @@ def test_joint_forward_matches_composition_of_reference_pieces():
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
-@pytest.mark.parametrize("name,B,N,d,hid", [("A", 64, 10, 32, 512), ("B", 256, 32, 256, 512)])
+@pytest.mark.parametrize("name,B,N,d,hid", [("A", 64, 10, 32, 512), ("B", 256, 32, 256, 512), ("C", 512, 64, 512, 512)])
 def test_named_config_training_step_matches_oracle(name, B, N, d, hid, mode):
-    """Reference defaults (A) and the mid-size configuration (B): losses, every gradient and the
-    parameters after one Adam step, against the oracle on the same weights, batch and eps."""
+    """Reference defaults (A), the mid-size configuration (B) and the headline configuration at full size
+    (C: 512 graphs, N=64, d=512): losses and every gradient, eager and graph replay, against the oracle on
+    the same weights, batch and eps."""
     from gtg_vae_amd.data import synth_graph_batch
     from gtg_vae_amd.trainer import GraphVAETrainer
     from oracle import graphvae_oracle as O
@@ -102,7 +103,18 @@ def test_named_config_training_step_matches_oracle(name, B, N, d, hid, mode):
         assert abs(res["recon"].item() - rec.item()) <= 1e-5 * abs(rec.item())
         assert abs(res["kl"].item() - kl.item()) <= 1e-5 * abs(kl.item()) + 1e-7
         for k in p:
-            assert _relerr(tr.named_grads()[k], p[k].grad) < 1e-4, (name, use_graph, k)
+            got, want = tr.named_grads()[k], p[k].grad
+            if name != "C":
+                assert _relerr(got, want) < 1e-4, (name, use_graph, k)
+            else:
+                # 512 x 512 max-pools over 64 rows: a few dozen winners lead the runner-up by less than 1e-6
+                # relative, and whichever side of such a tie a rounding error falls on moves 1/512 of one
+                # column's gradient to another row (measured: one such flip between the two matrix modes, 2e-4 of
+                # the largest entry).  So the entry-wise bound is looser here and the norm-wise one carries the
+                # check: a flip touches one column of dW2 and two rows of dZ1, real error would touch everything.
+                assert _relerr(got, want) < 1e-3, (name, use_graph, k)
+                g64, w64 = got.detach().double().cpu(), want.detach().double().cpu()
+                assert ((g64 - w64).norm() / w64.norm()).item() < 1e-4, (name, use_graph, k)
 
 
 def test_train_and_dev_loop_runs_and_learns(capsys):
