@@ -279,6 +279,8 @@ def main():
                     "pipe": ("v_mfma_f32_32x32x16_bf16, %d products per fp32 multiply-add" % MODE_PRODUCTS[args.matrix])
                             if on_bf16 else "v_mfma_f32_32x32x2_f32",
                     "fp32_equivalent_tflops": ach,
+                    # the same launch priced as what it computes (fp32 multiply-adds) against the fp32 matrix peak
+                    "fp32_equivalent_frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                     "launch": {"M": m_, "N": n_, "K": k_, "flops": fl, "avg_ms": avg_ms, "launches": cnt,
                                "stored_rows": eff_rows if ":" in name else None,
                                "timed_with": "HIP events on the launch stream, %s" % (
