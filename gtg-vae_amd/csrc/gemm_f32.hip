@@ -457,8 +457,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
         // K-group configurations run batch-sized GEMMs: a block sees only a handful of k steps, each far
         // shorter than a global load's latency, so the next FDEPTH tiles wait in registers (tile t in slot
         // t % FDEPTH, refilled with tile t + FDEPTH as soon as it has been written to LDS): the block pays
-        // the memory latency about once instead of once per k step.
-        constexpr int FDEPTH = 4;
+        // the memory latency about once instead of once per k step.  Three tiles: a fourth costs the
+        // 32x32 configuration a resident block per CU in registers and measured slower.
+        constexpr int FDEPTH = 3;
         f32x4 ra[FDEPTH][TA::NV], rb[FDEPTH][TB::NV];
 #pragma unroll
         for (int t = 0; t < FDEPTH; ++t) {
