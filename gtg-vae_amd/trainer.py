@@ -262,6 +262,10 @@ class GraphVAETrainer:
             segs += [None, lambda st: self._seg_encoder_backward(B, st)]
             if update:
                 segs += [None, lambda st: self._seg_adam(st)]
+        if self.world == 1:
+            # no all-reduce to place between the pieces: one segment, hence one HIP graph per step
+            parts = [f for f in segs if f is not None]
+            return [lambda st: [f(st) for f in parts]]
         return segs
 
     def _run_segments(self, runners, update: bool):
