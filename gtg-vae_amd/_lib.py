@@ -28,7 +28,7 @@ _SIGS = {
     "gtg_mst_batched_triu": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "gtg_mst_batched_full": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "gtg_edge_prf": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P]),
-    "gtg_adj_build": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, _P]),
+    "gtg_adj_build": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P]),
     "gtg_encoder_fwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     "gtg_encoder_fwd": (c_int, [_P] * 6 + [c_int64, c_int, c_int, c_int] + [_P] * 3 + [c_int, _P, c_size_t, _P]),
     "gtg_encoder_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),

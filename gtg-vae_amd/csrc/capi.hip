@@ -193,7 +193,7 @@ int gtg_edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gol
 // normalised adjacency from the ragged edge list
 // ---------------------------------------------------------------------------
 int gtg_adj_build(const int64_t* edge_index, int64_t num_edges, int64_t num_graphs, int n, int32_t* counts_ws,
-                  int32_t* err_flag, float* adj, void* stream)
+                  int32_t* err_flag, float* adj, int32_t* extents, void* stream)
 {
     GTG_REQUIRE(num_edges >= 0 && num_graphs >= 0, "negative size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
@@ -201,7 +201,7 @@ int gtg_adj_build(const int64_t* edge_index, int64_t num_edges, int64_t num_grap
     GTG_REQUIRE(counts_ws && err_flag && adj && (num_edges == 0 || edge_index), "null pointer");
     hipStream_t s = (hipStream_t)stream;
     GTG_TRY(adj_count(edge_index, num_edges, num_graphs, n, counts_ws, err_flag, s));
-    return adj_normalize(counts_ws, num_graphs, n, adj, s);
+    return adj_normalize(counts_ws, num_graphs, n, adj, extents, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -411,7 +411,7 @@ size_t gtg_encoder_compact_fwd_workspace_bytes(int64_t num_graphs, int n, int d)
     return c.off;
 }
 
-int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float* W1, const float* b1, const float* W2,
+int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const float* W1, const float* b1, const float* W2,
                             const float* b2, int64_t num_graphs, int n, int d, int32_t* meta, float* adjc, float* h1c,
                             float* pooled, int32_t* argmax, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
@@ -419,7 +419,7 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
-    GTG_REQUIRE(adj && counts && W1 && b1 && W2 && b2 && meta && adjc && h1c && pooled && argmax, "null pointer");
+    GTG_REQUIRE(adj && extents && W1 && b1 && W2 && b2 && meta && adjc && h1c && pooled && argmax, "null pointer");
     GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4, "batch too large");
     hipStream_t s = (hipStream_t)stream;
     const int B = (int)num_graphs, H = 2 * d, rows = B * n + n;
@@ -432,7 +432,7 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float
     const int32_t* real_rows = meta + 2 * B;      // R
     const int32_t* all_rows = meta + 2 * B + 1;   // R + n
 
-    GTG_TRY(graph_meta(counts, adj, B, n, meta, adjc, w.tail_cnt, (int)w.tail_cnt_count, s));
+    GTG_TRY(graph_meta(extents, adj, B, n, meta, adjc, w.tail_cnt, (int)w.tail_cnt_count, s));
     GemmDesc g;
     // H1c = relu(adjc * W1^T + b1) over the R + n stored rows: a graph's compact adjacency rows are zero past
     // its n_b columns, so one product with K = n serves every graph, and the unit rows appended to adjc give

@@ -38,20 +38,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm /* >= 4 floats
 // adjacency: counts[b][i][j] = #edges (src=j -> dst=i), self loops dropped.
 // Integer atomics: order-independent, exact.
 // ---------------------------------------------------------------------------
-// The clear is a kernel of this library rather than a memset so that a step
-// captured in a HIP graph replays it as an ordinary kernel node.
-__global__ __launch_bounds__(256) void adj_clear_kernel(int32_t* __restrict__ counts, int64_t total,
-                                                        int32_t* __restrict__ err)
-{
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i == 0) *err = 0;
-    if (i + 3 < total) {
-        *reinterpret_cast<int4*>(counts + i) = make_int4(0, 0, 0, 0);
-    } else {
-        for (int64_t j = i; j < total; ++j) counts[j] = 0;
-    }
-}
-
+// `counts` is all zero on entry (the caller zeroes it once, when it allocates it) and all zero again when
+// adj_normalize_kernel, its last reader, is done: no clearing launch per step.
 __global__ __launch_bounds__(256) void adj_count_kernel(const int64_t* __restrict__ ei, int64_t E, int64_t B, int n,
                                                         int32_t* __restrict__ counts, int32_t* __restrict__ err)
 {
@@ -197,26 +185,35 @@ __global__ __launch_bounds__(256) void clear_i32_kernel(int32_t* __restrict__ p,
 
 // One wave per graph (n <= 64): deg_i = 1 + sum_j counts[i][j];
 // adj[i][j] = deg_i^-1/2 * (counts[i][j] + [i==j]) * deg_j^-1/2.
-__global__ __launch_bounds__(64) void adj_normalize_kernel(const int32_t* __restrict__ counts, int n,
-                                                           float* __restrict__ adj)
+// On the way: extent[b] = 1 + the highest node index a (non-self) edge touches, 0 for a graph without
+// edges -- the number of encoder rows the compact-row layout stores for this graph -- and the graph's
+// counts are zeroed for the next batch (every element is read by the lane that then clears it).
+__global__ __launch_bounds__(64) void adj_normalize_kernel(int32_t* __restrict__ counts, int n,
+                                                           float* __restrict__ adj, int32_t* __restrict__ extent)
 {
     __shared__ float dis[64];
     const int64_t b = blockIdx.x;
     const int lane = threadIdx.x;
-    const int32_t* c = counts + b * n * n;
+    int32_t* c = counts + b * n * n;
     float* a = adj + b * n * n;
-    int deg = 1;
+    int deg = 1, touched = 0;
     if (lane < n)
         for (int j = 0; j < n; ++j) deg += c[lane * n + j];
+    touched = deg - 1;  // row `lane` holds an edge
     dis[lane] = (lane < n) ? 1.0f / sqrtf((float)deg) : 0.f;
     __syncthreads();
     if (lane < n) {
         const float dj = dis[lane];
         for (int i = 0; i < n; ++i) {
-            const float w = (float)(c[i * n + lane] + (i == lane ? 1 : 0));
+            const int cnt = c[i * n + lane];
+            touched |= cnt;  // column `lane` holds an edge
+            const float w = (float)(cnt + (i == lane ? 1 : 0));
             a[i * n + lane] = (dis[i] * w) * dj;
+            c[i * n + lane] = 0;
         }
     }
+    const unsigned long long m = __ballot(touched != 0);
+    if (extent != nullptr && lane == 0) extent[b] = m ? 64 - __clzll((long long)m) : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -392,66 +389,41 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
 // n extra nodes whose adjacency row is the unit vector, so every row-wise GEMM and
 // reduction of forward and backward covers them with no special case)
 // ---------------------------------------------------------------------------
-// (also clears `zero_count` int32 words at `zero`, the arrival counters of the GEMMs that follow: one
-// launch less than a separate clear)
-__global__ __launch_bounds__(64) void graph_extent_kernel(const int32_t* __restrict__ counts, int n,
-                                                          int32_t* __restrict__ n_real, int32_t* __restrict__ zero,
-                                                          int zero_count)
+// Block b < B: row offset of graph b = sum of the extents before it (every block adds them up itself: B
+// small integers, cheaper than a scan kernel in front of this one), meta[b] / meta[B + b], and
+// adjc[off + j, :] = adj[b, j, :] for j < n_b.  Block B: the totals meta[2B], meta[2B + 1] and the n unit rows
+// at R.  All blocks together clear `zero_count` int32 words at `zero`, the arrival counters of the GEMMs that
+// follow (one launch less than a separate clear).
+__global__ __launch_bounds__(256) void adj_compact_kernel(const float* __restrict__ adj, const int32_t* __restrict__ extent,
+                                                         int32_t* __restrict__ meta, int B, int n,
+                                                         float* __restrict__ adjc, int32_t* __restrict__ zero,
+                                                         int zero_count)
 {
-    const int64_t b = blockIdx.x;
-    const int lane = threadIdx.x;
-    for (int i = blockIdx.x * 64 + lane; i < zero_count; i += gridDim.x * 64) zero[i] = 0;
-    const int32_t* c = counts + b * n * n;
-    int touched = 0;
-    if (lane < n)
-        for (int j = 0; j < n; ++j) touched |= c[lane * n + j] | c[j * n + lane];
-    const unsigned long long m = __ballot(touched != 0);
-    if (lane == 0) n_real[b] = m ? 64 - __clzll((long long)m) : 0;
-}
-
-// exclusive scan of n_real over the batch (one block, ordered)
-__global__ __launch_bounds__(256) void graph_offsets_kernel(const int32_t* __restrict__ n_real, int B, int n,
-                                                            int32_t* __restrict__ off)
-{
-    __shared__ int part[256];
-    const int t = threadIdx.x;
-    const int per = (B + 255) / 256;
-    const int lo = t * per, hi = min(B, lo + per);
+    __shared__ int part[4];
+    const int b = blockIdx.x;
+    for (int i = b * 256 + threadIdx.x; i < zero_count; i += gridDim.x * 256) zero[i] = 0;
     int s = 0;
-    for (int b = lo; b < hi; ++b) s += n_real[b];
-    part[t] = s;
+    for (int g = threadIdx.x; g < b; g += 256) s += extent[g];  // b == B: all of them
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (t == 0) {
-        int run = 0;
-        for (int k = 0; k < 256; ++k) {
-            const int v = part[k];
-            part[k] = run;
-            run += v;
-        }
-        off[B] = run;          // R: rows of real nodes
-        off[B + 1] = run + n;  // R + n: the n prototype rows follow them
-    }
-    __syncthreads();
-    int run = part[t];
-    for (int b = lo; b < hi; ++b) {
-        off[b] = run;
-        run += n_real[b];
-    }
-}
-
-// adjc[off[b] + j, :] = adj[b, j, :] for j < n_b; block B writes the n identity rows at R
-__global__ __launch_bounds__(256) void adj_compact_kernel(const float* __restrict__ adj, const int32_t* __restrict__ meta,
-                                                         int64_t B, int n, float* __restrict__ adjc)
-{
-    const int64_t b = blockIdx.x;
+    const int off = part[0] + part[1] + part[2] + part[3];
     if (b == B) {
-        const int R = meta[2 * B];
+        if (threadIdx.x == 0) {
+            meta[2 * B] = off;          // R: rows of real nodes
+            meta[2 * B + 1] = off + n;  // R + n: the n prototype rows follow them
+        }
         for (int idx = threadIdx.x; idx < n * n; idx += 256)
-            adjc[(int64_t)R * n + idx] = (idx / n == idx % n) ? 1.f : 0.f;
+            adjc[(int64_t)off * n + idx] = (idx / n == idx % n) ? 1.f : 0.f;
         return;
     }
-    const int nb = meta[b], off = meta[B + b];
-    const float* src = adj + b * n * n;
+    const int nb = extent[b];
+    if (threadIdx.x == 0) {
+        meta[b] = nb;
+        meta[B + b] = off;
+    }
+    const float* src = adj + (int64_t)b * n * n;
     float* dst = adjc + (int64_t)off * n;
     for (int idx = threadIdx.x; idx < nb * n; idx += 256) dst[idx] = src[idx];
 }
@@ -668,10 +640,6 @@ __global__ __launch_bounds__(256) void edge_prf_kernel(const int32_t* __restrict
 // ===========================================================================
 int adj_count(const int64_t* ei, int64_t E, int64_t B, int n, int32_t* counts, int32_t* err, hipStream_t s)
 {
-    const int64_t total = B * n * n;
-    if (reinterpret_cast<uintptr_t>(counts) & 15) return set_error(GTG_ERR_INVALID, "adj_count: counts must be 16-byte aligned");
-    hipLaunchKernelGGL(adj_clear_kernel, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, s, counts, total, err);
-    if (const int rc = check_launch("adj_clear_kernel")) return rc;
     if (E == 0) return GTG_OK;
     hipLaunchKernelGGL(adj_count_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, ei, E, B, n, counts, err);
     return check_launch("adj_count_kernel");
@@ -709,10 +677,10 @@ int clear_i32(int32_t* p, int64_t count, hipStream_t s)
     return check_launch("clear_i32_kernel");
 }
 
-int adj_normalize(const int32_t* counts, int64_t B, int n, float* adj, hipStream_t s)
+int adj_normalize(int32_t* counts, int64_t B, int n, float* adj, int32_t* extent, hipStream_t s)
 {
     if (B == 0) return GTG_OK;
-    hipLaunchKernelGGL(adj_normalize_kernel, dim3((unsigned)B), dim3(64), 0, s, counts, n, adj);
+    hipLaunchKernelGGL(adj_normalize_kernel, dim3((unsigned)B), dim3(64), 0, s, counts, n, adj, extent);
     return check_launch("adj_normalize_kernel");
 }
 
@@ -811,17 +779,11 @@ int bce_bwd(const float* out, const float* adj, int64_t B, int n, const float* g
     return check_launch("bce_bwd_kernel");
 }
 
-int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, int32_t* zero,
+int graph_meta(const int32_t* extent, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, int32_t* zero,
                int zero_count, hipStream_t s)
 {
-    if (B == 0) return clear_i32(zero, zero_count, s);
-    hipLaunchKernelGGL(graph_extent_kernel, dim3((unsigned)B), dim3(64), 0, s, counts, n, meta, zero, zero_count);
-    int rc = check_launch("graph_extent_kernel");
-    if (rc) return rc;
-    hipLaunchKernelGGL(graph_offsets_kernel, dim3(1), dim3(256), 0, s, meta, (int)B, n, meta + B);
-    rc = check_launch("graph_offsets_kernel");
-    if (rc || adjc == nullptr) return rc;
-    hipLaunchKernelGGL(adj_compact_kernel, dim3((unsigned)B + 1), dim3(256), 0, s, adj, meta, B, n, adjc);
+    hipLaunchKernelGGL(adj_compact_kernel, dim3((unsigned)B + 1), dim3(256), 0, s, adj, extent, meta, (int)B, n, adjc, zero,
+                       zero_count);
     return check_launch("adj_compact_kernel");
 }
 

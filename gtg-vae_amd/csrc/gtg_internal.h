@@ -104,7 +104,9 @@ int gather_batch(const int64_t* esrc, int64_t E_all, const int64_t* estart, cons
                  const int64_t* idx, int B, int64_t* off, int64_t* ei_dst, int64_t E_cap, float* target_dst, int32_t* err,
                  hipStream_t s);
 int clear_i32(int32_t* p, int64_t count, hipStream_t s);  // a kernel, not a memset: replays correctly in HIP graphs
-int adj_normalize(const int32_t* counts, int64_t B, int n, float* adj, hipStream_t s);
+// counts: zero on entry to adj_count, zero again after adj_normalize; extent (nullable): per graph, 1 + the
+// highest node index an edge touches
+int adj_normalize(int32_t* counts, int64_t B, int n, float* adj, int32_t* extent, hipStream_t s);
 int pool_bwd_gather(const float* adj, const float* dpool, const int32_t* argmax, int64_t B, int n, int d,
                     float* dT2, hipStream_t s);
 int colsum(const float* X, int64_t rows, int cols, int ld, float* partial, float* out, hipStream_t s);
@@ -115,7 +117,7 @@ int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int 
 // compact node rows (identity features): meta = [n_b (B) | row offsets (B+1) | R + n], adjc = compact adjacency
 // rows followed by n identity rows (the prototype rows)
 // zero / zero_count: int32 words cleared by the same launches (the tail-split arrival counters)
-int graph_meta(const int32_t* counts, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, int32_t* zero,
+int graph_meta(const int32_t* extent, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, int32_t* zero,
                int zero_count, hipStream_t s);
 int proto_suffix_max(const float* t2c, const int32_t* row_base, const float* b2, int n, int d, float* sval,
                      int32_t* sidx, hipStream_t s);

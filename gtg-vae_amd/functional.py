@@ -29,25 +29,27 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 # adjacency
 # ---------------------------------------------------------------------------
 def build_adj(edge_index: torch.Tensor, num_graphs: int, nmax: int, check_edges: bool = False,
-              return_counts: bool = False):
+              return_extents: bool = False):
     """D^-1/2 (C + I) D^-1/2 per graph, (B, nmax, nmax) fp32, from a PyG-style
     batched edge_index (2, E) int64.  With check_edges the error flag is read
     back (a host sync) and an exception raised if an edge leaves its graph.
-    With return_counts the raw (B*n*n) int32 edge counts are returned as well
-    (the compact encoder derives each graph's extent from them)."""
+    With return_extents the per-graph extents (B) int32 are returned as well
+    (1 + the highest node index an edge touches: the rows the compact encoder
+    stores; EncoderFn's ``extents`` argument)."""
     _lib.require_cuda(edge_index)
     ei = edge_index.contiguous()
     if ei.dtype != torch.int64:
         ei = ei.long()
     dev = ei.device
-    counts = torch.empty((num_graphs * nmax * nmax,), dtype=torch.int32, device=dev)
-    err = torch.empty((1,), dtype=torch.int32, device=dev)
+    counts = torch.zeros((num_graphs * nmax * nmax,), dtype=torch.int32, device=dev)  # zero in, zero out
+    err = torch.zeros((1,), dtype=torch.int32, device=dev)
     adj = torch.empty((num_graphs, nmax, nmax), dtype=torch.float32, device=dev)
-    check(_lib.lib().gtg_adj_build(ptr(ei), ei.shape[1], num_graphs, nmax, ptr(counts), ptr(err), ptr(adj), stream_ptr()),
-          "gtg_adj_build")
+    extents = torch.empty((num_graphs,), dtype=torch.int32, device=dev)
+    check(_lib.lib().gtg_adj_build(ptr(ei), ei.shape[1], num_graphs, nmax, ptr(counts), ptr(err), ptr(adj),
+                                   ptr(extents), stream_ptr()), "gtg_adj_build")
     if check_edges and int(err.item()) != 0:
         raise _lib.GtgError("edge_index holds an edge whose endpoints are out of range or in different graphs")
-    return (adj, counts) if return_counts else adj
+    return (adj, extents) if return_extents else adj
 
 
 # ---------------------------------------------------------------------------
@@ -57,7 +59,7 @@ class EncoderFn(torch.autograd.Function):
     """pooled (B, d) = global_max_pool(GCN2(relu(GCN1(x))))."""
 
     @staticmethod
-    def forward(ctx, adj, x, W1, b1, W2, b2, counts=None, matrix_mode=None):
+    def forward(ctx, adj, x, W1, b1, W2, b2, extents=None, matrix_mode=None):
         L = _lib.lib()
         ctx.mode = mode = _lib.matrix_mode(matrix_mode)
         adj, x, W1, b1, W2, b2 = map(_f32c, (adj, x, W1, b1, W2, b2))
@@ -69,7 +71,7 @@ class EncoderFn(torch.autograd.Function):
         if x is not None and tuple(x.shape) != (B * n, f):
             raise _lib.GtgError(f"x must be (B*n, f) = ({B * n}, {f}), got {tuple(x.shape)}")
         dev = adj.device
-        ctx.compact = x is None and counts is not None and f == n
+        ctx.compact = x is None and extents is not None and f == n
         if ctx.compact:
             # identity features: only the rows an edge touches are stored and multiplied
             meta = torch.empty((2 * B + 2,), dtype=torch.int32, device=dev)
@@ -78,7 +80,7 @@ class EncoderFn(torch.autograd.Function):
             pooled = torch.empty((B, d), dtype=torch.float32, device=dev)
             argmax = torch.empty((B, d), dtype=torch.int32, device=dev)
             ws = _ws(L.gtg_encoder_compact_fwd_workspace_bytes(B, n, d), dev)
-            check(L.gtg_encoder_compact_fwd(ptr(adj), ptr(counts), ptr(W1), ptr(b1), ptr(W2), ptr(b2), B, n, d,
+            check(L.gtg_encoder_compact_fwd(ptr(adj), ptr(extents), ptr(W1), ptr(b1), ptr(W2), ptr(b2), B, n, d,
                                             ptr(meta), ptr(adjc), ptr(h1c), ptr(pooled), ptr(argmax), mode, ptr(ws),
                                             ws.numel(), stream_ptr()), "gtg_encoder_compact_fwd")
             ctx.save_for_backward(adj, adjc, meta, W2, h1c, argmax)

@@ -66,11 +66,11 @@ class VGAE_encoder(nn.Module):
         never written to memory.  ``x`` may be None for stacked identities."""
         if nmax is None or num_graphs is None:
             raise _lib.GtgError("VGAE_encoder.forward needs num_graphs and nmax (graphs are padded to nmax nodes)")
-        counts = None
+        extents = None
         if adj is None:
-            adj, counts = Fn.build_adj(edge_index, num_graphs, nmax, return_counts=True)
+            adj, extents = Fn.build_adj(edge_index, num_graphs, nmax, return_extents=True)
         pooled, self.last_argmax = Fn.EncoderFn.apply(adj, x, self.conv1.lin.weight, self.conv1.bias,
-                                                      self.conv2.lin.weight, self.conv2.bias, counts,
+                                                      self.conv2.lin.weight, self.conv2.bias, extents,
                                                       getattr(self, "matrix_mode", None))
         return pooled
 

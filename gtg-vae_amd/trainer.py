@@ -135,7 +135,7 @@ class GraphVAETrainer:
         L, dev, n, d, hid, m, f = self.L, self.dev, self.n, self.d, self.hid, self.m, self.f
         f32 = dict(dtype=torch.float32, device=dev)
         self.ei = torch.zeros((2, E), dtype=torch.int64, device=dev)
-        self.counts = torch.empty(B * n * n, dtype=torch.int32, device=dev)
+        self.counts = torch.zeros(B * n * n, dtype=torch.int32, device=dev)  # zero in, zero out (gtg_adj_build)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         self.gather_err = torch.zeros(1, dtype=torch.int32, device=dev)
         self.gather_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
@@ -207,11 +207,12 @@ class GraphVAETrainer:
         L, n, d, hid, m = self.L, self.n, self.d, self.hid, self.m
         p = self.p
         ws, wsn = ptr(self.ws), self.ws.numel()
-        check(L.gtg_adj_build(ptr(self.ei), self.ei.shape[1], B, n, ptr(self.counts), ptr(self.err), ptr(self.adj),
-                              stream), "gtg_adj_build")
-        # meta is carved per call: [n_b (B) | offsets (B+1) | R + n] for THIS batch size
+        # meta is carved per call: [n_b (B) | offsets (B+1) | R + n] for THIS batch size; the adjacency
+        # build leaves the graphs' extents n_b in its first B words
         meta = self.meta[: 2 * B + 2]
-        check(L.gtg_encoder_compact_fwd(ptr(self.adj), ptr(self.counts), ptr(p["encoder.conv1.lin.weight"]),
+        check(L.gtg_adj_build(ptr(self.ei), self.ei.shape[1], B, n, ptr(self.counts), ptr(self.err), ptr(self.adj),
+                              ptr(meta), stream), "gtg_adj_build")
+        check(L.gtg_encoder_compact_fwd(ptr(self.adj), ptr(meta), ptr(p["encoder.conv1.lin.weight"]),
                                         ptr(p["encoder.conv1.bias"]), ptr(p["encoder.conv2.lin.weight"]),
                                         ptr(p["encoder.conv2.bias"]), B, n, d, ptr(meta), ptr(self.adjc), ptr(self.h1),
                                         ptr(self.pooled), ptr(self.argmax), self.matrix_mode, ws, wsn, stream),

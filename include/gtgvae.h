@@ -89,11 +89,17 @@ int gtg_edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gol
  * src/graph_vae.py:107,110: self loops dropped, one unit self loop per node,
  * in-degree with multiplicity, D^-1/2 (C + I) D^-1/2.
  *   edge_index (2, E) int64, PyG batch numbering (node id = graph*n + local)
- *   counts_ws (B*n*n) int32 scratch, err_flag (1) int32: set to 1 if an edge
- *   leaves its graph or is out of range;  adj (B, n, n) fp32 output,
- *   adj[b,i,j] = weight with which node j feeds node i. */
+ *   counts_ws (B*n*n) int32 scratch, 16-byte aligned: ALL ZERO on entry -- zero
+ *   it once when it is allocated -- and left all zero (the call that reads
+ *   the counts last clears them, so a step needs no clearing launch);
+ *   err_flag (1) int32, zeroed by the caller: set to 1 if an edge leaves its
+ *   graph or is out of range, never cleared by the library;
+ *   adj (B, n, n) fp32 output, adj[b,i,j] = weight with which node j feeds
+ *   node i;  extents (B) int32 output, may be NULL: 1 + the highest node index
+ *   a non-self edge of graph b touches (0: no edge), the row count the
+ *   compact-row encoder stores for the graph. */
 int gtg_adj_build(const int64_t* edge_index, int64_t num_edges, int64_t num_graphs, int n, int32_t* counts_ws,
-                  int32_t* err_flag, float* adj, void* stream);
+                  int32_t* err_flag, float* adj, int32_t* extents, void* stream);
 
 /* ---- encoder -------------------------------------------------------------
  * Replaces VGAE_encoder.forward (src/graph_vae.py:106-110: GCNConv, ReLU,
@@ -120,12 +126,12 @@ int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const flo
  * vector), and merged into the max-pool as a suffix maximum.  Results equal
  * gtg_encoder_fwd/bwd with x = NULL; the row-proportional GEMMs shrink from
  * B*n to R + n rows.
- *   counts  (B*n*n) int32: the scratch gtg_adj_build filled on this stream
+ *   extents (B) int32: as written by gtg_adj_build (may be the first B words of meta)
  *   meta    (2B+2)  int32 out: n_b per graph, B+1 exclusive row offsets (last = R), R + n
  *   adjc    (B*n + n, n) out: compact adjacency rows, then the n unit rows
  *   h1c     (B*n + n, 2d) out: first R + n rows valid */
 size_t gtg_encoder_compact_fwd_workspace_bytes(int64_t num_graphs, int n, int d);
-int gtg_encoder_compact_fwd(const float* adj, const int32_t* counts, const float* W1, const float* b1, const float* W2,
+int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const float* W1, const float* b1, const float* W2,
                             const float* b2, int64_t num_graphs, int n, int d, int32_t* meta, float* adjc, float* h1c,
                             float* pooled, int32_t* argmax, int matrix_mode, void* ws, size_t ws_bytes, void* stream);
 size_t gtg_encoder_compact_bwd_workspace_bytes(int64_t num_graphs, int n, int d);

@@ -41,5 +41,5 @@ def test_bad_arguments_are_reported_not_crashed():
     l = _lib.lib()
     rc = l.gtg_mst_batched_triu(None, 4, 65, None, None, None)
     assert rc == -3 and b"64" in l.gtg_last_error()
-    rc = l.gtg_adj_build(None, 0, 2, 0, None, None, None, None)
+    rc = l.gtg_adj_build(None, 0, 2, 0, None, None, None, None, None)
     assert rc == -1

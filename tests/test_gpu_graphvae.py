@@ -49,6 +49,37 @@ def test_adj_build_matches_oracle(B, N):
     assert torch.allclose(got.cpu(), want, rtol=1e-6, atol=1e-7)
 
 
+def test_adj_build_extents_and_reusable_counts_scratch():
+    """gtg_adj_build leaves its counts scratch all zero (two different batches through the same
+    buffers give two right answers) and reports each graph's extent: 1 + the highest node index a
+    non-self edge touches, 0 without edges."""
+    from gtg_vae_amd import _lib
+    from gtg_vae_amd._lib import check, ptr, stream_ptr
+    from gtg_vae_amd.data import synth_graph_batch
+    from oracle import graphvae_oracle as O
+
+    B, N = 9, 12
+    counts = torch.zeros(B * N * N, dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    adj = torch.empty(B, N, N, device="cuda")
+    ext = torch.empty(B, dtype=torch.int32, device="cuda")
+    for seed in (3, 4):
+        ei = synth_graph_batch(B, N, seed=seed).edge_index
+        if seed == 4:  # graph 0 loses its edges, graph 1 keeps self loops only
+            keep = (ei[0] // N > 1)
+            ei = torch.cat([ei[:, keep], torch.tensor([[N + 2, N + 5], [N + 2, N + 5]])], 1)
+        check(_lib.lib().gtg_adj_build(ptr(ei.cuda()), ei.shape[1], B, N, ptr(counts), ptr(err), ptr(adj), ptr(ext),
+                                       stream_ptr()), "gtg_adj_build")
+        assert torch.allclose(adj.cpu(), O.gcn_dense_adj(ei, B, N), rtol=1e-6, atol=1e-7)
+        assert int(counts.abs().sum()) == 0 and int(err.item()) == 0
+        want = torch.zeros(B, dtype=torch.int32)
+        for s_, t_ in ei.t().tolist():
+            if s_ != t_:
+                g = s_ // N
+                want[g] = max(int(want[g]), s_ % N + 1, t_ % N + 1)
+        assert torch.equal(ext.cpu(), want)
+
+
 def test_adj_build_flags_cross_graph_edges():
     from gtg_vae_amd import functional as Fn
     from gtg_vae_amd._lib import GtgError
@@ -74,8 +105,8 @@ def test_encoder_forward_backward(B, N, d, hid, identity_x):
 
     names = ["encoder.conv1.lin.weight", "encoder.conv1.bias", "encoder.conv2.lin.weight", "encoder.conv2.bias"]
     gp = [p[k].detach().cuda().requires_grad_(True) for k in names]
-    adj, counts = Fn.build_adj(batch.edge_index.cuda(), B, N, return_counts=True)
-    got, argmax = Fn.EncoderFn.apply(adj, None if x is None else x.cuda(), *gp, counts)
+    adj, extents = Fn.build_adj(batch.edge_index.cuda(), B, N, return_extents=True)
+    got, argmax = Fn.EncoderFn.apply(adj, None if x is None else x.cuda(), *gp, extents)
     assert _relerr(got, want) < 1e-5
     (got * up.cuda()).sum().backward()
     for k, t in zip(names, gp):
@@ -105,12 +136,12 @@ def test_compact_encoder_edge_cases(N, d):
     up = torch.randn(B, d, generator=torch.Generator().manual_seed(4))
     (want * up).sum().backward()
     names = ["encoder.conv1.lin.weight", "encoder.conv1.bias", "encoder.conv2.lin.weight", "encoder.conv2.bias"]
-    adj, counts = Fn.build_adj(ei.cuda(), B, N, return_counts=True)
+    adj, extents = Fn.build_adj(ei.cuda(), B, N, return_extents=True)
     outs = []
     for compact in (True, False):
         gp = [p[k].detach().cuda().requires_grad_(True) for k in names]
         x = None if compact else torch.eye(N).repeat(B, 1).cuda()
-        got, am = Fn.EncoderFn.apply(adj, x, *gp, counts if compact else None)
+        got, am = Fn.EncoderFn.apply(adj, x, *gp, extents if compact else None)
         assert _relerr(got, want) < 1e-5, compact
         (got * up.cuda()).sum().backward()
         for k, t in zip(names, gp):
@@ -137,8 +168,8 @@ def test_compact_encoder_on_dense_graphs_and_odd_widths(N, d):
     (want * up).sum().backward()
     names = ["encoder.conv1.lin.weight", "encoder.conv1.bias", "encoder.conv2.lin.weight", "encoder.conv2.bias"]
     gp = [p[k].detach().cuda().requires_grad_(True) for k in names]
-    adj, counts = Fn.build_adj(ei.cuda(), B, N, return_counts=True)
-    got, _ = Fn.EncoderFn.apply(adj, None, *gp, counts)
+    adj, extents = Fn.build_adj(ei.cuda(), B, N, return_extents=True)
+    got, _ = Fn.EncoderFn.apply(adj, None, *gp, extents)
     assert _relerr(got, want) < 1e-5
     (got * up.cuda()).sum().backward()
     for k, t in zip(names, gp):

@@ -18,13 +18,13 @@ W1 = torch.randn(2 * d, N, device="cuda") * 0.1
 b1 = torch.randn(2 * d, device="cuda") * 0.1
 W2 = torch.randn(d, 2 * d, device="cuda") * 0.05
 b2 = torch.zeros(d, device="cuda")
-adj, counts = Fn.build_adj(gb.edge_index, B, N, return_counts=True)
+adj, extents = Fn.build_adj(gb.edge_index, B, N, return_extents=True)
 for _ in range(3):
-    Fn.EncoderFn.apply(adj, None, W1, b1, W2, b2, counts, "bf16x3")
+    Fn.EncoderFn.apply(adj, None, W1, b1, W2, b2, extents, "bf16x3")
 torch.cuda.synchronize()
 _lib.profile_enable(True)
 for _ in range(20):
-    Fn.EncoderFn.apply(adj, None, W1, b1, W2, b2, counts, "bf16x3")
+    Fn.EncoderFn.apply(adj, None, W1, b1, W2, b2, extents, "bf16x3")
 torch.cuda.synchronize()
 for k, a, b, c, n, ms in _lib.profile_report():
     print("%-16s %6d %6d %6d  x%d  %.1f us" % (k, a, b, c, n, ms / n * 1e3))
