@@ -519,7 +519,6 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     // dT2c: real rows from the max-pool routing, prototype rows from the graphs whose maximum they won
     GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, w.tail_cnt, (int)w.tail_cnt_count, s));
     GTG_TRY(proto_grad(dpooled, argmax, meta, B, n, d, w.pg, w.dT2c, s));
-    GTG_TRY(colsum(dpooled, B, d, d, w.cs, db2, s));
     GemmDesc g;
     // dW2 = dT2c^T * H1c
     g.A = w.dT2c; g.lda = d; g.a_kc = false;
@@ -535,7 +534,8 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     g.epi = EPI_MASK; g.aux = h1c; g.ldaux = H;
     g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
     GTG_TRY(gemm(g, s));
-    GTG_TRY(colsum_dev(w.dZ1c, rows, all_rows, H, H, w.cs, db1, s));
+    // db1 = column sums of dZ1c (two stages); db2 = column sums of dpooled rides in the second stage's launch
+    GTG_TRY(colsum_dev_and_short(w.dZ1c, rows, all_rows, H, H, w.cs, db1, dpooled, B, d, d, db2, s));
     // dW1[c][i] = sum over stored rows dZ1c[r][c] * adjc[r][i]   (prototype rows carry unit adjacency rows)
     g = GemmDesc();
     g.A = w.dZ1c; g.lda = H; g.a_kc = false;
@@ -614,8 +614,7 @@ int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const flo
         g.batch = 2; g.strideA = dlv - dmu; g.strideB = 0; g.strideC = dWlv - dWmu;
         GTG_TRY(gemm(g, s));
     }
-    GTG_TRY(colsum(dmu, B, d, d, cs, dbmu, s));
-    GTG_TRY(colsum(dlv, B, d, d, cs, dblv, s));
+    GTG_TRY(colsum_pair(dmu, B, d, d, dbmu, dlv, B, d, d, dblv, cs, s));
     // dh = dmu * Wmu + dlogvar * Wlv
     g = GemmDesc();
     g.A = dmu; g.lda = d; g.a_kc = true;
@@ -744,7 +743,6 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
     g.C = dD2; g.ldc = hid; g.M = m_out; g.N = hid; g.K = B;
     g.splits = gemm_pick_splits(m_out, hid, B, 1); g.slabs = w.slabs;
     GTG_TRY(gemm(g, s));
-    GTG_TRY(colsum(w.dy2, B, m_out, m_out, w.cs, dc2, s));
     // dy1 = (dy2 * D2) masked by relu
     g = GemmDesc();
     g.A = w.dy2; g.lda = m_out; g.a_kc = true;
@@ -759,7 +757,8 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
     g.C = dD1; g.ldc = d; g.M = hid; g.N = d; g.K = B;
     g.splits = gemm_pick_splits(hid, d, B, 1); g.slabs = w.slabs;
     GTG_TRY(gemm(g, s));
-    GTG_TRY(colsum(w.dy1, B, hid, hid, w.cs, dc1, s));
+    // both bias gradients in one launch: dc2 = column sums of dy2, dc1 of dy1
+    GTG_TRY(colsum_pair(w.dy2, B, m_out, m_out, dc2, w.dy1, B, hid, hid, dc1, w.cs, s));
     // dz = dy1 * D1
     g = GemmDesc();
     g.A = w.dy1; g.lda = hid; g.a_kc = true;

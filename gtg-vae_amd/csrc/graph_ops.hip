@@ -286,6 +286,46 @@ __global__ __launch_bounds__(16 * CS_RL) void colsum_kernel(const float* __restr
     }
 }
 
+// Two short column sums in one launch (blockIdx.z picks the job): bias gradients that become available at
+// different points of a backward pass but are needed only at its end share a kernel boundary.
+struct ColsumJob {
+    const float* X;
+    float* out;
+    int rows, cols, ld, vec;
+};
+
+__global__ __launch_bounds__(1024) void colsum_pair_kernel(const ColsumJob j0, const ColsumJob j1)
+{
+    constexpr int RL = 64;
+    __shared__ f32x4 sm[RL][CS_COLS / 4];
+    const ColsumJob j = blockIdx.z == 0 ? j0 : j1;
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * CS_COLS + cg * 4;
+    if (blockIdx.x * CS_COLS >= j.cols) return;  // block-uniform: this job is narrower than the grid
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (col < j.cols) {
+        if (j.vec && col + 3 < j.cols) {
+#pragma unroll 8
+            for (int r = rl; r < j.rows; r += RL) s += *reinterpret_cast<const f32x4*>(j.X + (long long)r * j.ld + col);
+        } else {
+            for (int r = rl; r < j.rows; r += RL)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (col + q < j.cols) s[q] += j.X[(long long)r * j.ld + col + q];
+        }
+    }
+    sm[rl][cg] = s;
+    __syncthreads();
+    if (rl == 0 && col < j.cols) {
+        f32x4 t = sm[0][cg];
+#pragma unroll
+        for (int k = 1; k < RL; ++k) t += sm[k][cg];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (col + q < j.cols) j.out[col + q] = t[q];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // z = eps * exp(0.5 logvar) + mu ;  KL = -0.5 * sum(1 + logvar - mu^2 - e^logvar) / B
 // ---------------------------------------------------------------------------
@@ -728,6 +768,40 @@ int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int 
     hipLaunchKernelGGL(colsum_kernel<16>, dim3((cols + CS_COLS - 1) / CS_COLS, 1), dim3(256), 0, s, partial,
                        (int64_t)nchunks, cols, cols, nchunks, vec2, (const int*)nullptr, out);
     return check_launch("colsum_kernel");
+}
+
+// out0 = column sums of X0 (rows0 x cols0), out1 likewise, in one launch when both are a single chunk
+// (at most 1024 rows); otherwise two ordinary column sums through `partial`.
+int colsum_pair(const float* X0, int64_t rows0, int cols0, int ld0, float* out0, const float* X1, int64_t rows1,
+                int cols1, int ld1, float* out1, float* partial, hipStream_t s)
+{
+    if (rows0 > 1024 || rows1 > 1024 || rows0 < 1 || rows1 < 1 || cols0 < 1 || cols1 < 1) {
+        if (int rc = colsum(X0, rows0, cols0, ld0, partial, out0, s)) return rc;
+        return colsum(X1, rows1, cols1, ld1, partial, out1, s);
+    }
+    ColsumJob j0{X0, out0, (int)rows0, cols0, ld0, ((reinterpret_cast<uintptr_t>(X0) & 15) == 0) && (ld0 % 4 == 0)};
+    ColsumJob j1{X1, out1, (int)rows1, cols1, ld1, ((reinterpret_cast<uintptr_t>(X1) & 15) == 0) && (ld1 % 4 == 0)};
+    const int wide = cols0 > cols1 ? cols0 : cols1;
+    hipLaunchKernelGGL(colsum_pair_kernel, dim3((wide + CS_COLS - 1) / CS_COLS, 1, 2), dim3(1024), 0, s, j0, j1);
+    return check_launch("colsum_pair_kernel");
+}
+
+// Column sums of a tall matrix X (rows read on the device) and of a short one X2: the short one rides in the
+// launch of the tall one's second stage (three launches become two).
+int colsum_dev_and_short(const float* X, int64_t rows, const int* rows_dev, int cols, int ld, float* partial, float* out,
+                         const float* X2, int64_t rows2, int cols2, int ld2, float* out2, hipStream_t s)
+{
+    const int chunk = cs_chunk_rows(rows);
+    const int nchunks = (int)((rows + chunk - 1) / chunk);
+    if (nchunks <= 1 || nchunks > 1024 || rows2 > 1024 || rows2 < 1 || cols < 1 || cols2 < 1) {
+        if (int rc = colsum_dev(X, rows, rows_dev, cols, ld, partial, out, s)) return rc;
+        return colsum(X2, rows2, cols2, ld2, partial, out2, s);  // partial is free again
+    }
+    const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ld % 4 == 0);
+    hipLaunchKernelGGL(colsum_kernel<16>, dim3((cols + CS_COLS - 1) / CS_COLS, nchunks), dim3(256), 0, s, X, rows, cols, ld,
+                       chunk, vec, rows_dev, partial);
+    if (int rc = check_launch("colsum_kernel")) return rc;
+    return colsum_pair(partial, nchunks, cols, cols, out, X2, rows2, cols2, ld2, out2, nullptr, s);
 }
 
 int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z, float* kl_partial,

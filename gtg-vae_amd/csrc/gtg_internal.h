@@ -111,6 +111,12 @@ int pool_bwd_gather(const float* adj, const float* dpool, const int32_t* argmax,
                     float* dT2, hipStream_t s);
 int colsum(const float* X, int64_t rows, int cols, int ld, float* partial, float* out, hipStream_t s);
 size_t colsum_workspace(int64_t rows, int cols);
+// column sums of a tall matrix and of a short one, the short one riding in the tall one's second-stage launch
+int colsum_dev_and_short(const float* X, int64_t rows, const int* rows_dev, int cols, int ld, float* partial, float* out,
+                         const float* X2, int64_t rows2, int cols2, int ld2, float* out2, hipStream_t s);
+// two column sums in one launch when both matrices have at most 1024 rows (else two launches through `partial`)
+int colsum_pair(const float* X0, int64_t rows0, int cols0, int ld0, float* out0, const float* X1, int64_t rows1,
+                int cols1, int ld1, float* out1, float* partial, hipStream_t s);
 // rows = min(rows, *rows_dev) when rows_dev is given (row count known only on the device)
 int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int ld, float* partial, float* out,
                hipStream_t s);
