@@ -481,7 +481,8 @@ static void enc_cbwd_layout(Carver& c, int64_t B, int n, int d, EncCBwdWs* w)
     w->dT2c = c.take<float>(rows * d);
     w->dZ1c = c.take<float>(rows * H);
     w->pg = reinterpret_cast<float*>(c.take<char>(proto_grad_workspace(n, d)));
-    w->cs = reinterpret_cast<float*>(c.take<char>(max2(colsum_workspace(B, d), colsum_workspace((int64_t)rows, H))));
+    w->cs = reinterpret_cast<float*>(c.take<char>(max2(max2(colsum_workspace(B, d), colsum_workspace((int64_t)rows, H)),
+                                                       (size_t)gemm_colsum_rows((int)rows) * H * sizeof(float))));
     w->slabs = reinterpret_cast<float*>(
         c.take<char>(max2(gemm_splitk_workspace(d, H, (int)rows, 1), gemm_splitk_workspace(H, n, (int)rows, 1))));
     size_t tb, cb;
@@ -533,9 +534,16 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     g.C = w.dZ1c; g.ldc = H; g.M = rows; g.N = H; g.K = d; g.m_dev = all_rows;
     g.epi = EPI_MASK; g.aux = h1c; g.ldaux = H;
     g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
+    // db1 = column sums of dZ1c: the GEMM's epilogue leaves them per 64-row block (no pass over dZ1c for them), one
+    // launch adds the blocks and, beside them, db2 = column sums of dpooled.  Needs the 128x128 configuration and at
+    // most 1024 blocks and graphs; otherwise a two-stage column sum over dZ1c.
+    const bool fused_db1 = gemm_colsum_rows(rows) <= 1024 && B <= 1024 && (long long)((rows + 127) / 128) * ((H + 127) / 128) >= 192;
+    if (fused_db1) g.colsum_part = w.cs;
     GTG_TRY(gemm(g, s));
-    // db1 = column sums of dZ1c (two stages); db2 = column sums of dpooled rides in the second stage's launch
-    GTG_TRY(colsum_dev_and_short(w.dZ1c, rows, all_rows, H, H, w.cs, db1, dpooled, B, d, d, db2, s));
+    if (fused_db1)
+        GTG_TRY(colsum_parts_and_short(w.cs, gemm_colsum_rows(rows), all_rows, H, db1, dpooled, B, d, d, db2, nullptr, s));
+    else
+        GTG_TRY(colsum_dev_and_short(w.dZ1c, rows, all_rows, H, H, w.cs, db1, dpooled, B, d, d, db2, s));
     // dW1[c][i] = sum over stored rows dZ1c[r][c] * adjc[r][i]   (prototype rows carry unit adjacency rows)
     g = GemmDesc();
     g.A = w.dZ1c; g.lda = H; g.a_kc = false;

@@ -53,6 +53,7 @@ struct KArgs {
     float* tail_ws;         // tail split: accumulator slabs, one per (tail tile, part)
     int32_t* tail_counters; // arrivals per tail tile
     int tail_slots;         // resident block slots of the device for this kernel
+    float* colsum_part;     // optional: column sums of C per wave row-block, (tiles_m * WAVES_M, N)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).
@@ -837,6 +838,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
             xv[it] = t;
         }
     }
+    f32x4 colacc = {0.f, 0.f, 0.f, 0.f};  // this lane's share of the column sums of the stored values
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int lrow = it * RPI + rsub;
@@ -857,6 +859,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
             }
             v[q] = y;
         }
+        colacc += v;
         float* dst = C + (long long)grow * ldc + gcol;
         if (vec_ok) {
             *reinterpret_cast<f32x4*>(dst) = v;
@@ -864,6 +867,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (gcol + q < a.N) dst[q] = v[q];
+        }
+    }
+    // Column sums of what this wave stored (its WTM rows x WTN columns), rows in a fixed order: a bias
+    // gradient then needs no pass of its own over C, only the sum of these per-row-block partials.
+    if (a.colsum_part != nullptr && !a.to_slabs) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) colacc[q] += __shfl_xor(colacc[q], o);
+        if (rsub == 0 && gcol < a.N) {
+            float* dst = a.colsum_part + (long long)(tm * WAVES_M + wm / WTM) * a.N + gcol;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (gcol + q < a.N) dst[q] = colacc[q];
         }
     }
 }
@@ -1041,6 +1058,12 @@ int gemm(const GemmDesc& d, hipStream_t s)
     k.tail_ws = nullptr;
     k.tail_counters = nullptr;
     k.tail_slots = 0;
+    k.colsum_part = nullptr;
+    if (d.colsum_part != nullptr) {
+        if (cfg != CFG_128 || splits != 1 || d.batch != 1 || d.epi == EPI_POOL)
+            return set_error(GTG_ERR_INVALID, "gemm: column sums ride only on the 128x128 configuration, batch 1, no split-K");
+        k.colsum_part = d.colsum_part;
+    }
     long long grid = (long long)k.tiles_m * k.tiles_n * splits * d.batch;
     static const bool tail_off = getenv("GTG_GEMM_TAIL") && atoi(getenv("GTG_GEMM_TAIL")) == 0;  // experiment hook
     if (!tail_off && d.tail_ws != nullptr && d.tail_counters != nullptr && cfg == CFG_128 && d.batch == 1 && splits == 1 &&

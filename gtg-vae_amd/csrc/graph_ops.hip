@@ -292,13 +292,16 @@ struct ColsumJob {
     const float* X;
     float* out;
     int rows, cols, ld, vec;
+    const int* rows_dev;  // optional: rows = min(rows, mult * ceil(*rows_dev / unit))
+    int unit, mult;
 };
 
 __global__ __launch_bounds__(1024) void colsum_pair_kernel(const ColsumJob j0, const ColsumJob j1)
 {
     constexpr int RL = 64;
     __shared__ f32x4 sm[RL][CS_COLS / 4];
-    const ColsumJob j = blockIdx.z == 0 ? j0 : j1;
+    ColsumJob j = blockIdx.z == 0 ? j0 : j1;
+    if (j.rows_dev) j.rows = min(j.rows, j.mult * ((j.rows_dev[0] + j.unit - 1) / j.unit));
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int col = blockIdx.x * CS_COLS + cg * 4;
     if (blockIdx.x * CS_COLS >= j.cols) return;  // block-uniform: this job is narrower than the grid
@@ -779,9 +782,29 @@ int colsum_pair(const float* X0, int64_t rows0, int cols0, int ld0, float* out0,
         if (int rc = colsum(X0, rows0, cols0, ld0, partial, out0, s)) return rc;
         return colsum(X1, rows1, cols1, ld1, partial, out1, s);
     }
-    ColsumJob j0{X0, out0, (int)rows0, cols0, ld0, ((reinterpret_cast<uintptr_t>(X0) & 15) == 0) && (ld0 % 4 == 0)};
-    ColsumJob j1{X1, out1, (int)rows1, cols1, ld1, ((reinterpret_cast<uintptr_t>(X1) & 15) == 0) && (ld1 % 4 == 0)};
+    ColsumJob j0{X0, out0, (int)rows0, cols0, ld0, ((reinterpret_cast<uintptr_t>(X0) & 15) == 0) && (ld0 % 4 == 0),
+                 nullptr, 1, 1};
+    ColsumJob j1{X1, out1, (int)rows1, cols1, ld1, ((reinterpret_cast<uintptr_t>(X1) & 15) == 0) && (ld1 % 4 == 0),
+                 nullptr, 1, 1};
     const int wide = cols0 > cols1 ? cols0 : cols1;
+    hipLaunchKernelGGL(colsum_pair_kernel, dim3((wide + CS_COLS - 1) / CS_COLS, 1, 2), dim3(1024), 0, s, j0, j1);
+    return check_launch("colsum_pair_kernel");
+}
+
+// out = sum of the per-row-block column sums a GEMM epilogue left in `part` (gemm_colsum_rows(M) x cols; with a
+// device-side row count only the blocks of live tiles are valid) and out2 = column sums of the short matrix X2.
+int colsum_parts_and_short(const float* part, int part_rows, const int* gemm_rows_dev, int cols, float* out,
+                           const float* X2, int64_t rows2, int cols2, int ld2, float* out2, float* partial,
+                           hipStream_t s)
+{
+    if (part_rows > 1024 || part_rows < 1 || rows2 > 1024 || rows2 < 1 || cols < 1 || cols2 < 1)
+        return set_error(GTG_ERR_UNSUPPORTED, "colsum_parts_and_short: more than 1024 rows");
+    (void)partial;
+    ColsumJob j0{part, out, part_rows, cols, cols, ((reinterpret_cast<uintptr_t>(part) & 15) == 0) && (cols % 4 == 0),
+                 gemm_rows_dev, 128, 2};
+    ColsumJob j1{X2, out2, (int)rows2, cols2, ld2, ((reinterpret_cast<uintptr_t>(X2) & 15) == 0) && (ld2 % 4 == 0),
+                 nullptr, 1, 1};
+    const int wide = cols > cols2 ? cols : cols2;
     hipLaunchKernelGGL(colsum_pair_kernel, dim3((wide + CS_COLS - 1) / CS_COLS, 1, 2), dim3(1024), 0, s, j0, j1);
     return check_launch("colsum_pair_kernel");
 }

@@ -74,7 +74,11 @@ struct GemmDesc {
     // zero again on exit.  Sizes: gemm_tail_workspace().
     float* tail_ws = nullptr;
     int32_t* tail_counters = nullptr;
+    // 128x128 configuration only: the epilogue also leaves the column sums of the rows each wave stored, as
+    // colsum_part[(tile row * 2 + wave row)][N] (gemm_colsum_rows(M) rows; with m_dev only those of live tiles)
+    float* colsum_part = nullptr;
 };
+inline int gemm_colsum_rows(int M) { return 2 * ((M + 127) / 128); }
 
 // Matrix pipe of the MFMA-bound (128x128-tile) GEMMs issued by the calling thread: GTG_MATRIX_F32
 // (v_mfma_f32_32x32x2_f32), GTG_MATRIX_BF16 (operands rounded to bf16) or GTG_MATRIX_BF16X3 (exact
@@ -114,6 +118,10 @@ size_t colsum_workspace(int64_t rows, int cols);
 // column sums of a tall matrix and of a short one, the short one riding in the tall one's second-stage launch
 int colsum_dev_and_short(const float* X, int64_t rows, const int* rows_dev, int cols, int ld, float* partial, float* out,
                          const float* X2, int64_t rows2, int cols2, int ld2, float* out2, hipStream_t s);
+// out = sum of a GEMM epilogue's per-row-block column sums (GemmDesc::colsum_part), out2 = column sums of X2
+int colsum_parts_and_short(const float* part, int part_rows, const int* gemm_rows_dev, int cols, float* out,
+                           const float* X2, int64_t rows2, int cols2, int ld2, float* out2, float* partial,
+                           hipStream_t s);
 // two column sums in one launch when both matrices have at most 1024 rows (else two launches through `partial`)
 int colsum_pair(const float* X0, int64_t rows0, int cols0, int ld0, float* out0, const float* X1, int64_t rows1,
                 int cols1, int ld1, float* out1, float* partial, hipStream_t s);
