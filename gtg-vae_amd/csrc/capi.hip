@@ -681,15 +681,15 @@ size_t gtg_bce_workspace_bytes(int64_t num_graphs)
     return c.off;
 }
 
-int gtg_bce_loss_fwd(const float* out, const float* adj_target, int64_t num_graphs, int n, float* loss, void* ws,
-                     size_t ws_bytes, void* stream)
+int gtg_bce_loss_fwd(const float* out, const float* adj_target, int64_t num_graphs, int n, float* loss, float* dlogits,
+                     void* ws, size_t ws_bytes, void* stream)
 {
     GTG_REQUIRE(num_graphs >= 1 && n >= 1, "bad size");
     GTG_REQUIRE(out && adj_target && loss, "null pointer");
     Carver c(ws, ws_bytes);
     float* partial = c.take<float>((size_t)num_graphs + 1);
     if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_bce_loss_fwd: workspace too small");
-    return bce_fwd(out, adj_target, num_graphs, n, partial, loss, (hipStream_t)stream);
+    return bce_fwd(out, adj_target, num_graphs, n, partial, loss, dlogits, (hipStream_t)stream);
 }
 
 int gtg_bce_loss_bwd(const float* out, const float* adj_target, float gscale, const float* gscale_dev,
@@ -730,8 +730,9 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
                     float* dz, void* ws, size_t ws_bytes, void* stream)
 {
     GTG_REQUIRE(num_graphs >= 1 && d >= 1 && hid >= 1 && m_out >= 1, "bad size");
-    GTG_REQUIRE(z && D1 && D2 && y1 && out && dD1 && dc1 && dD2 && dc2 && dz, "null pointer");
+    GTG_REQUIRE(z && D1 && D2 && y1 && dD1 && dc1 && dD2 && dc2 && dz, "null pointer");
     GTG_REQUIRE((dout != nullptr) != (adj_target != nullptr), "give exactly one of dout / adj_target");
+    GTG_REQUIRE(out != nullptr || dout != nullptr, "out may be NULL only when dout holds the gradient w.r.t. the logits");
     GTG_REQUIRE(adj_target == nullptr || m_out == n * (n + 1) / 2, "m_out must be n(n+1)/2 with fused BCE");
     hipStream_t s = (hipStream_t)stream;
     const int B = (int)num_graphs;
@@ -740,20 +741,23 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
     dec_bwd_layout(c, B, d, hid, m_out, &w);
     if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_decoder_bwd: workspace too small");
 
+    const float* dy2 = w.dy2;
     if (adj_target)
         GTG_TRY(bce_bwd(out, adj_target, B, n, gscale_dev, gscale, 1, w.dy2, s));
-    else
+    else if (out)
         GTG_TRY(sigmoid_bwd(out, dout, (int64_t)B * m_out, w.dy2, s));
+    else
+        dy2 = dout;  // already the gradient w.r.t. the logits (gtg_bce_loss_fwd's dlogits)
     GemmDesc g;
     // dD2 = dy2^T * y1
-    g.A = w.dy2; g.lda = m_out; g.a_kc = false;
+    g.A = dy2; g.lda = m_out; g.a_kc = false;
     g.B = y1; g.ldb = hid; g.b_kc = false;
     g.C = dD2; g.ldc = hid; g.M = m_out; g.N = hid; g.K = B;
     g.splits = gemm_pick_splits(m_out, hid, B, 1); g.slabs = w.slabs;
     GTG_TRY(gemm(g, s));
     // dy1 = (dy2 * D2) masked by relu
     g = GemmDesc();
-    g.A = w.dy2; g.lda = m_out; g.a_kc = true;
+    g.A = dy2; g.lda = m_out; g.a_kc = true;
     g.B = D2; g.ldb = hid; g.b_kc = false;
     g.C = w.dy1; g.ldc = hid; g.M = B; g.N = hid; g.K = m_out;
     g.epi = EPI_MASK; g.aux = y1; g.ldaux = hid;
@@ -766,7 +770,7 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
     g.splits = gemm_pick_splits(hid, d, B, 1); g.slabs = w.slabs;
     GTG_TRY(gemm(g, s));
     // both bias gradients in one launch: dc2 = column sums of dy2, dc1 of dy1
-    GTG_TRY(colsum_pair(w.dy2, B, m_out, m_out, dc2, w.dy1, B, hid, hid, dc1, w.cs, s));
+    GTG_TRY(colsum_pair(dy2, B, m_out, m_out, dc2, w.dy1, B, hid, hid, dc1, w.cs, s));
     // dz = dy1 * D1
     g = GemmDesc();
     g.A = w.dy1; g.lda = hid; g.a_kc = true;

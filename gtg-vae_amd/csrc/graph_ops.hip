@@ -378,8 +378,11 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
 // Element k = i*n - i(i-1)/2 + (j-i), i <= j, of row b of `out` pairs with
 // adj[b,i,j].  log terms clamp at -100 (binary_cross_entropy semantics).
 // ---------------------------------------------------------------------------
+// (dlogits, when given, receives the gradient of the mean loss w.r.t. the pre-sigmoid logits in the same
+// pass: gl / (B m) with gl as in bce_bwd_kernel below.)
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ out, const float* __restrict__ adj,
-                                                      int n, int m, float* __restrict__ row_partial)
+                                                      int n, int m, float* __restrict__ row_partial, float gscale,
+                                                      float* __restrict__ dlogits)
 {
     __shared__ float sm[4];
     const int64_t b = blockIdx.x;
@@ -394,6 +397,10 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
         const float lp = fmaxf(logf(p), -100.f);
         const float lq = fmaxf(logf(1.f - p), -100.f);
         s += (t - 1.f) * lq - t * lp;
+        if (dlogits != nullptr) {
+            const float q = (1.f - p) * p;
+            dlogits[b * m + k] = (gscale * (p - t) / fmaxf(q, 1e-12f)) * q;
+        }
     }
     const float tot = block_sum_256(s, sm);
     if (threadIdx.x == 0) row_partial[b] = tot;
@@ -853,11 +860,13 @@ int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const
     return check_launch("latent_bwd_kernel");
 }
 
-int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, hipStream_t s)
+int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, float* dlogits,
+            hipStream_t s)
 {
     const int m = n * (n + 1) / 2;
     if (B > 0) {
-        hipLaunchKernelGGL(bce_fwd_kernel, dim3((unsigned)B), dim3(256), 0, s, out, adj, n, m, row_partial);
+        hipLaunchKernelGGL(bce_fwd_kernel, dim3((unsigned)B), dim3(256), 0, s, out, adj, n, m, row_partial,
+                           m > 0 ? 1.f / ((float)B * (float)m) : 0.f, dlogits);
         int rc = check_launch("bce_fwd_kernel");
         if (rc) return rc;
     }

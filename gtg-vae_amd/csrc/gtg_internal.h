@@ -144,7 +144,9 @@ int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B
                float* kl_partial, float* kl_out, hipStream_t s);
 int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const float* eps, const float* kl_scale_dev,
                     float kl_scale, int64_t B, int d, float* dmu, float* dlogvar, hipStream_t s);
-int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, hipStream_t s);
+// dlogits (nullable): gradient of the mean loss w.r.t. the pre-sigmoid logits, written in the same pass
+int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, float* dlogits,
+            hipStream_t s);
 // gdev (nullable) is a device scalar multiplied into gscale (an upstream gradient).
 // through_sigmoid = 1: gradient w.r.t. the pre-sigmoid logits (BCE backward, then
 // the sigmoid's backward); 0: gradient w.r.t. the probabilities only.

@@ -152,6 +152,7 @@ class GraphVAETrainer:
         self.z = torch.empty((B, d), **f32)
         self.y1 = torch.empty((B, hid), **f32)
         self.out = torch.empty((B, m), **f32)
+        self.dlogits = torch.empty((B, m), **f32)  # d(recon loss)/d(decoder logits), written by the loss kernel
         self.dz = torch.empty((B, d), **f32)
         self.dh = torch.empty((B, d), **f32)
         self.scalars = torch.zeros(2, **f32)  # [recon, kl]
@@ -203,7 +204,7 @@ class GraphVAETrainer:
     # The step is three runs of launches with the two gradient all-reduces between
     # them; each run can be replayed as a HIP graph while the collectives stay
     # ordinary stream work.
-    def _seg_forward(self, B: int, stream: int):
+    def _seg_forward(self, B: int, stream: int, backward: bool = True):
         L, n, d, hid, m = self.L, self.n, self.d, self.hid, self.m
         p = self.p
         ws, wsn = ptr(self.ws), self.ws.numel()
@@ -223,8 +224,9 @@ class GraphVAETrainer:
         check(L.gtg_decoder_fwd(ptr(self.z), ptr(p["decoder.decode_1.weight"]), ptr(p["decoder.decode_1.bias"]),
                                 ptr(p["decoder.decode_2.weight"]), ptr(p["decoder.decode_2.bias"]), B, d, hid, m,
                                 ptr(self.y1), ptr(self.out), stream), "gtg_decoder_fwd")
-        check(L.gtg_bce_loss_fwd(ptr(self.out), ptr(self.target), B, n, self.scalars.data_ptr(), ws, wsn, stream),
-              "gtg_bce_loss_fwd")
+        # with a backward to follow, the loss kernel leaves its gradient w.r.t. the logits on the way
+        check(L.gtg_bce_loss_fwd(ptr(self.out), ptr(self.target), B, n, self.scalars.data_ptr(),
+                                 ptr(self.dlogits) if backward else None, ws, wsn, stream), "gtg_bce_loss_fwd")
 
     def _seg_head_backward(self, B: int, stream: int):
         """Decoder and latent head: their gradients (bucket 0) are final after this."""
@@ -232,7 +234,7 @@ class GraphVAETrainer:
         p, g = self.p, self.g
         ws, wsn = ptr(self.ws), self.ws.numel()
         check(L.gtg_decoder_bwd(ptr(self.z), ptr(p["decoder.decode_1.weight"]), ptr(p["decoder.decode_2.weight"]),
-                                ptr(self.y1), ptr(self.out), None, ptr(self.target), n, 1.0, None, B, d, hid, m,
+                                ptr(self.y1), None, ptr(self.dlogits), None, n, 1.0, None, B, d, hid, m,
                                 ptr(g["decoder.decode_1.weight"]), ptr(g["decoder.decode_1.bias"]),
                                 ptr(g["decoder.decode_2.weight"]), ptr(g["decoder.decode_2.bias"]), ptr(self.dz), ws,
                                 wsn, stream), "gtg_decoder_bwd")
@@ -258,7 +260,7 @@ class GraphVAETrainer:
 
     def _segments(self, B: int, update: bool, backward: bool = True):
         """The step as a list of callables(stream), with None where an all-reduce goes."""
-        segs = [lambda st: (self._seg_forward(B, st), backward and self._seg_head_backward(B, st))]
+        segs = [lambda st: (self._seg_forward(B, st, backward), backward and self._seg_head_backward(B, st))]
         if backward:
             segs += [None, lambda st: self._seg_encoder_backward(B, st)]
             if update:
