@@ -560,8 +560,7 @@ size_t gtg_latent_workspace_bytes(int64_t num_graphs, int d)
 {
     Carver c(nullptr, 0);
     c.take<float>((size_t)((num_graphs * d + 255) / 256) + 1);          // KL block partials
-    c.take<float>((size_t)num_graphs * d);                               // dmu
-    c.take<float>((size_t)num_graphs * d);                               // dlogvar
+    c.take<float>((size_t)2 * num_graphs * d);                           // dmu, dlogvar
     c.take<char>(colsum_workspace(num_graphs, d));
     c.take<char>(gemm_splitk_workspace(d, d, (int)num_graphs, 1));
     return c.off;
@@ -599,17 +598,22 @@ int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const flo
     const int B = (int)num_graphs;
     Carver c(ws, ws_bytes);
     c.take<float>((size_t)((num_graphs * d + 255) / 256) + 1);
-    float* dmu = c.take<float>((size_t)B * d);
-    float* dlv = c.take<float>((size_t)B * d);
+    float* dboth = c.take<float>((size_t)2 * B * d);
     float* cs = reinterpret_cast<float*>(c.take<char>(colsum_workspace(B, d)));
     float* slabs = reinterpret_cast<float*>(c.take<char>(gemm_splitk_workspace(d, d, B, 1)));
     if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_latent_bwd: workspace too small");
+    // When the two weight matrices lie back to back in memory, [Wmu; Wlv] is one (2d, d) operand: dmu and dlogvar
+    // are then kept as the halves of (B, 2d) rows and dh = [dmu | dlogvar] [Wmu; Wlv] is a single GEMM.
+    const bool stacked = (Wlv == Wmu + (size_t)d * d);
+    const int ld = stacked ? 2 * d : d;
+    float* dmu = dboth;
+    float* dlv = stacked ? dboth + d : dboth + (size_t)B * d;
 
-    GTG_TRY(latent_bwd_elem(dz, mu, logvar, eps, kl_w_dev, kl_w, B, d, dmu, dlv, s));
+    GTG_TRY(latent_bwd_elem(dz, mu, logvar, eps, kl_w_dev, kl_w, B, d, ld, dmu, dlv, s));
     const int splits = gemm_pick_splits(d, d, B, 1);
     GemmDesc g;
     // dW = dY^T * h
-    g.A = dmu; g.lda = d; g.a_kc = false;
+    g.A = dmu; g.lda = ld; g.a_kc = false;
     g.B = h; g.ldb = d; g.b_kc = false;
     g.C = dWmu; g.ldc = d; g.M = d; g.N = d; g.K = B;
     if (splits > 1) {
@@ -618,17 +622,18 @@ int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const flo
         g.A = dlv; g.C = dWlv;
         GTG_TRY(gemm(g, s));
     } else {
-        // both weight gradients in one launch (dmu and dlv are adjacent in the workspace)
+        // both weight gradients in one launch
         g.batch = 2; g.strideA = dlv - dmu; g.strideB = 0; g.strideC = dWlv - dWmu;
         GTG_TRY(gemm(g, s));
     }
-    GTG_TRY(colsum_pair(dmu, B, d, d, dbmu, dlv, B, d, d, dblv, cs, s));
+    GTG_TRY(colsum_pair(dmu, B, d, ld, dbmu, dlv, B, d, ld, dblv, cs, s));
     // dh = dmu * Wmu + dlogvar * Wlv
     g = GemmDesc();
-    g.A = dmu; g.lda = d; g.a_kc = true;
+    g.A = dmu; g.lda = ld; g.a_kc = true;
     g.B = Wmu; g.ldb = d; g.b_kc = false;
-    g.C = dh; g.ldc = d; g.M = B; g.N = d; g.K = d;
+    g.C = dh; g.ldc = d; g.M = B; g.N = d; g.K = stacked ? 2 * d : d;
     GTG_TRY(gemm(g, s));
+    if (stacked) return GTG_OK;
     g.A = dlv; g.B = Wlv; g.epi = EPI_ACCUM;
     return gemm(g, s);
 }
@@ -651,7 +656,7 @@ int gtg_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, c
 {
     GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(mu && logvar && eps && dmu && dlogvar, "null pointer");
-    return latent_bwd_elem(dz, mu, logvar, eps, kl_w_dev, kl_w, num_graphs, d, dmu, dlogvar, (hipStream_t)stream);
+    return latent_bwd_elem(dz, mu, logvar, eps, kl_w_dev, kl_w, num_graphs, d, d, dmu, dlogvar, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

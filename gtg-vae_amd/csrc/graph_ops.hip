@@ -362,15 +362,16 @@ __global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mu,
                                                          const float* __restrict__ lv, const float* __restrict__ eps,
                                                          const float* __restrict__ kl_w_dev, float kl_w, float inv_b,
-                                                         int64_t total, float* __restrict__ dmu,
+                                                         int64_t total, int d, int ld, float* __restrict__ dmu,
                                                          float* __restrict__ dlv)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const float w = (kl_w_dev ? kl_w_dev[0] * kl_w : kl_w) * inv_b;
     const float m = mu[i], l = lv[i], g = dz ? dz[i] : 0.f;
-    dmu[i] = g + w * m;
-    dlv[i] = g * (0.5f * eps[i] * expf(0.5f * l)) + w * 0.5f * (expf(l) - 1.f);
+    const int64_t o = (i / d) * ld + (i % d);  // the outputs may be the two halves of (B, 2d) rows
+    dmu[o] = g + w * m;
+    dlv[o] = g * (0.5f * eps[i] * expf(0.5f * l)) + w * 0.5f * (expf(l) - 1.f);
 }
 
 // ---------------------------------------------------------------------------
@@ -851,12 +852,12 @@ int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B
 }
 
 int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const float* eps, const float* kl_w_dev,
-                    float kl_w, int64_t B, int d, float* dmu, float* dlogvar, hipStream_t s)
+                    float kl_w, int64_t B, int d, int ld_out, float* dmu, float* dlogvar, hipStream_t s)
 {
     const int64_t total = B * d;
     if (total == 0) return GTG_OK;
     hipLaunchKernelGGL(latent_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dz, mu, logvar, eps,
-                       kl_w_dev, kl_w, 1.f / (float)B, total, dmu, dlogvar);
+                       kl_w_dev, kl_w, 1.f / (float)B, total, d, ld_out, dmu, dlogvar);
     return check_launch("latent_bwd_kernel");
 }
 

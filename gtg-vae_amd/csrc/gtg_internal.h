@@ -142,8 +142,9 @@ int proto_grad(const float* dpool, const int32_t* argmax, const int32_t* meta, i
                float* dT2c, hipStream_t s);
 int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z,
                float* kl_partial, float* kl_out, hipStream_t s);
+// dmu / dlogvar rows have stride ld_out (d, or 2d when they are the two halves of one (B, 2d) matrix)
 int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const float* eps, const float* kl_scale_dev,
-                    float kl_scale, int64_t B, int d, float* dmu, float* dlogvar, hipStream_t s);
+                    float kl_scale, int64_t B, int d, int ld_out, float* dmu, float* dlogvar, hipStream_t s);
 // dlogits (nullable): gradient of the mean loss w.r.t. the pre-sigmoid logits, written in the same pass
 int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, float* dlogits,
             hipStream_t s);

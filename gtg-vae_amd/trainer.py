@@ -26,9 +26,10 @@ _PARAM_ORDER = (
     ("decoder.decode_1.bias", lambda f, d, h, m: (h,)),
     ("decoder.decode_2.weight", lambda f, d, h, m: (m, h)),
     ("decoder.decode_2.bias", lambda f, d, h, m: (m,)),
+    # the two latent weight matrices back to back: gtg_latent_bwd then multiplies by [Wmu; Wlv] in one GEMM
     ("zg_mu.weight", lambda f, d, h, m: (d, d)),
-    ("zg_mu.bias", lambda f, d, h, m: (d,)),
     ("zg_var.weight", lambda f, d, h, m: (d, d)),
+    ("zg_mu.bias", lambda f, d, h, m: (d,)),
     ("zg_var.bias", lambda f, d, h, m: (d,)),
     ("encoder.conv1.lin.weight", lambda f, d, h, m: (2 * d, f)),
     ("encoder.conv1.bias", lambda f, d, h, m: (2 * d,)),
