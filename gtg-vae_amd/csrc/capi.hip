@@ -386,8 +386,8 @@ int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const flo
 // path, with the row-proportional GEMMs shrunk to the real rows.
 // ---------------------------------------------------------------------------
 struct EncCFwdWs {
-    float *t2c, *sval, *tail;
-    int32_t *sidx, *tail_cnt;
+    float *t2c, *tail;
+    int32_t* tail_cnt;
     size_t tail_cnt_count;
 };
 
@@ -396,8 +396,6 @@ static void enc_cfwd_layout(Carver& c, int64_t B, int n, int d, EncCFwdWs* w)
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);
     w->t2c = c.take<float>((size_t)(B * n + n) * d);
-    w->sval = c.take<float>((size_t)(n + 1) * d);
-    w->sidx = c.take<int32_t>((size_t)(n + 1) * d);
     w->tail = reinterpret_cast<float*>(c.take<char>(tb));
     w->tail_cnt = reinterpret_cast<int32_t*>(c.take<char>(cb));
     w->tail_cnt_count = cb / sizeof(int32_t);
@@ -455,16 +453,15 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const floa
     g.M = rows; g.N = d; g.K = H; g.m_dev = all_rows;
     g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
     GTG_TRY(gemm(g, s));
-    // suffix maxima (+ b2) of the prototype rows over the row index
-    GTG_TRY(proto_suffix_max(w.t2c, real_rows, b2, n, d, w.sval, w.sidx, s));
-    // pooled[b] = max( max_{i<n_b}(A_b * T2c[b] + b2), suffix max of the prototype rows from n_b )
+    // pooled[b] = max( max_{i<n_b}(A_b * T2c[b] + b2), max of the prototype rows from n_b on (+ b2) ): the
+    // epilogue reads those rows of T2c itself
     g = GemmDesc();
     g.A = adj; g.lda = n; g.a_kc = true; g.strideA = (long long)n * n;
     g.B = w.t2c; g.ldb = d; g.b_kc = false; g.off_b = true;
     g.M = n; g.N = d; g.K = n; g.batch = B;
     g.batch_dim = n_real; g.batch_off = row_off;
     g.bias = b2; g.epi = EPI_POOL; g.pool_val = pooled; g.pool_idx = argmax;
-    g.proto_val = w.sval; g.proto_idx = w.sidx;
+    g.proto_base = real_rows;
     return gemm(g, s);
 }
 

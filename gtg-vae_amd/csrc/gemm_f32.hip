@@ -47,8 +47,7 @@ struct KArgs {
     const int* batch_dim;  // optional per-batch M = K (ragged block-diagonal operands)
     const int* batch_off;  // optional per-batch row offset of B and/or C (compact node rows)
     int off_b, off_c;
-    const float* proto_val;  // pooled epilogue: value / row index to merge per (batch_dim[batch], col)
-    const int32_t* proto_idx;
+    const int* proto_base;   // pooled epilogue: row of B where the M prototype rows start (device scalar)
     int to_slabs;  // write raw partials to C viewed as [batch*splits][M][N]
     float* tail_ws;         // tail split: accumulator slabs, one per (tail tile, part)
     int32_t* tail_counters; // arrivals per tail tile
@@ -702,12 +701,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
                     best = ob;
                     bi = oi;
                 }
-                if (a.proto_val != nullptr && col < a.N) {
-                    // rows past this graph's real nodes all equal batch-independent prototype rows:
-                    // merge their precomputed suffix maximum (a real row wins ties: lower index)
+                if (a.proto_base != nullptr) {
+                    // rows past this graph's real nodes all equal batch-independent prototype rows, stored once
+                    // after the real rows of the B operand: take their maximum from row n_b on (lowest index on
+                    // ties; the two half-waves share a column and split the rows) and merge it -- a real row
+                    // wins ties (lower index).  The bias is added as to the real rows.
                     const int nb = a.batch_dim[batch];
-                    const float pv = a.proto_val[(long long)nb * a.N + col];
-                    const int pi = a.proto_idx[(long long)nb * a.N + col];
+                    float pv = 0.f;
+                    int pi = -1;
+                    if (col < a.N) {
+                        const float* Q = a.B + (long long)a.proto_base[0] * a.ldb + col;
+#pragma unroll 4
+                        for (int i = nb + h; i < a.M; i += 2) {
+                            const float v = Q[(long long)i * a.ldb] + bias;
+                            if (pi < 0 || v > pv) {
+                                pv = v;
+                                pi = i;
+                            }
+                        }
+                    }
+                    const float qv = __shfl_xor(pv, 32);
+                    const int qi = __shfl_xor(pi, 32);
+                    if (qi >= 0 && (pi < 0 || qv > pv || (qv == pv && qi < pi))) {
+                        pv = qv;
+                        pi = qi;
+                    }
                     if (pi >= 0 && (bi < 0 || pv > best)) {
                         best = pv;
                         bi = pi;
@@ -1029,8 +1047,7 @@ int gemm(const GemmDesc& d, hipStream_t s)
     k.batch_off = d.batch_off;
     k.off_b = d.off_b ? 1 : 0;
     k.off_c = d.off_c ? 1 : 0;
-    k.proto_val = d.proto_val;
-    k.proto_idx = d.proto_idx;
+    k.proto_base = d.proto_base;
     k.vecA = ((reinterpret_cast<uintptr_t>(d.A) & 15) == 0) && (d.lda % 4 == 0) && (d.strideA % 4 == 0);
     k.vecB = ((reinterpret_cast<uintptr_t>(d.B) & 15) == 0) && (d.ldb % 4 == 0) && (d.strideB % 4 == 0);
 

@@ -479,32 +479,6 @@ __global__ __launch_bounds__(256) void adj_compact_kernel(const float* __restric
     for (int idx = threadIdx.x; idx < nb * n; idx += 256) dst[idx] = src[idx];
 }
 
-// S[k][c] = max_{i >= k} Q[i][c] with its row index (lowest index on ties); S[n] = none
-__global__ __launch_bounds__(256) void proto_suffix_max_kernel(const float* __restrict__ t2c,
-                                                               const int32_t* __restrict__ row_base,
-                                                               const float* __restrict__ b2, int n, int d,
-                                                               float* __restrict__ sval, int32_t* __restrict__ sidx)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d) return;
-    const float* Q = t2c + (int64_t)row_base[0] * d;
-    const float bias = b2[c];
-    float best = 0.f;
-    int bi = -1;
-    sval[(int64_t)n * d + c] = 0.f;
-    sidx[(int64_t)n * d + c] = -1;
-#pragma unroll 8
-    for (int i = n - 1; i >= 0; --i) {
-        const float v = Q[(int64_t)i * d + c] + bias;
-        if (bi < 0 || v >= best) {
-            best = v;
-            bi = i;
-        }
-        sval[(int64_t)i * d + c] = best;
-        sidx[(int64_t)i * d + c] = bi;
-    }
-}
-
 // max-pool backward for compact rows: dT2c[off_b + j, c] = adj[b, am, j] * dpool[b,c], j < n_b
 // (zero when the winning row am is a prototype row: it has no edge to a stored row)
 __global__ __launch_bounds__(256) void pool_bwd_gather_compact_kernel(const float* __restrict__ adj,
@@ -892,14 +866,6 @@ int graph_meta(const int32_t* extent, const float* adj, int64_t B, int n, int32_
     hipLaunchKernelGGL(adj_compact_kernel, dim3((unsigned)B + 1), dim3(256), 0, s, adj, extent, meta, (int)B, n, adjc, zero,
                        zero_count);
     return check_launch("adj_compact_kernel");
-}
-
-int proto_suffix_max(const float* t2c, const int32_t* row_base, const float* b2, int n, int d, float* sval,
-                     int32_t* sidx, hipStream_t s)
-{
-    hipLaunchKernelGGL(proto_suffix_max_kernel, dim3((d + 255) / 256), dim3(256), 0, s, t2c, row_base, b2, n, d, sval,
-                       sidx);
-    return check_launch("proto_suffix_max_kernel");
 }
 
 int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,

@@ -59,8 +59,9 @@ struct GemmDesc {
     const int* batch_dim = nullptr;  // per batch: M = K = batch_dim[b]
     const int* batch_off = nullptr;  // per batch: row offset applied to B (off_b) and/or C and aux (off_c)
     bool off_b = false, off_c = false;
-    const float* proto_val = nullptr;    // EPI_POOL: ((max batch_dim)+1, N) values merged at row batch_dim[b]
-    const int32_t* proto_idx = nullptr;  //           and their row indices (-1 = none)
+    // EPI_POOL: B holds M batch-independent "prototype" rows from row *proto_base on (off_b offsets aside); the
+    // maximum over prototype rows batch_dim[b] .. M-1 (+ bias) is merged into batch b's pool
+    const int* proto_base = nullptr;
     // split-K: when splits > 1 the kernel writes `splits` partial slabs of
     // M*N floats into `slabs` and a second kernel sums them in slab order into C
     // (bitwise reproducible; no float atomics).
@@ -133,8 +134,6 @@ int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int 
 // zero / zero_count: int32 words cleared by the same launches (the tail-split arrival counters)
 int graph_meta(const int32_t* extent, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, int32_t* zero,
                int zero_count, hipStream_t s);
-int proto_suffix_max(const float* t2c, const int32_t* row_base, const float* b2, int n, int d, float* sval,
-                     int32_t* sidx, hipStream_t s);
 int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,
                             int64_t B, int n, int d, float* dT2, int32_t* zero, int zero_count, hipStream_t s);
 size_t proto_grad_workspace(int n, int d);
