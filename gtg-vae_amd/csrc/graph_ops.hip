@@ -183,37 +183,55 @@ __global__ __launch_bounds__(256) void clear_i32_kernel(int32_t* __restrict__ p,
     if (i < count) p[i] = 0;
 }
 
-// One wave per graph (n <= 64): deg_i = 1 + sum_j counts[i][j];
+// One block per graph (n <= 64): deg_i = 1 + sum_j counts[i][j];
 // adj[i][j] = deg_i^-1/2 * (counts[i][j] + [i==j]) * deg_j^-1/2.
 // On the way: extent[b] = 1 + the highest node index a (non-self) edge touches, 0 for a graph without
 // edges -- the number of encoder rows the compact-row layout stores for this graph -- and the graph's
 // counts are zeroed for the next batch (every element is read by the lane that then clears it).
-__global__ __launch_bounds__(64) void adj_normalize_kernel(int32_t* __restrict__ counts, int n,
-                                                           float* __restrict__ adj, int32_t* __restrict__ extent)
+__global__ __launch_bounds__(256) void adj_normalize_kernel(int32_t* __restrict__ counts, int n,
+                                                            float* __restrict__ adj, int32_t* __restrict__ extent)
 {
+    __shared__ int cs[64 * 65];  // the graph's counts, row stride 65: rows and columns both read conflict-free
     __shared__ float dis[64];
     const int64_t b = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t* c = counts + b * n * n;
     float* a = adj + b * n * n;
-    int deg = 1, touched = 0;
-    if (lane < n)
-        for (int j = 0; j < n; ++j) deg += c[lane * n + j];
-    touched = deg - 1;  // row `lane` holds an edge
-    dis[lane] = (lane < n) ? 1.0f / sqrtf((float)deg) : 0.f;
-    __syncthreads();
-    if (lane < n) {
-        const float dj = dis[lane];
-        for (int i = 0; i < n; ++i) {
-            const int cnt = c[i * n + lane];
-            touched |= cnt;  // column `lane` holds an edge
-            const float w = (float)(cnt + (i == lane ? 1 : 0));
-            a[i * n + lane] = (dis[i] * w) * dj;
+    const int lane_c = min(lane, n - 1);
+    // four waves take the rows in turn: one coalesced read per row, then the row is cleared for the next batch
+    // (unconditional loads at clamped indices; the rows' loads are all in flight before the first LDS write)
+    int v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = c[min(wave + 4 * t, n - 1) * n + lane_c];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int i = wave + 4 * t;
+        if (i < n && lane < n) {
+            cs[i * 65 + lane] = v[t];
             c[i * n + lane] = 0;
         }
     }
-    const unsigned long long m = __ballot(touched != 0);
-    if (extent != nullptr && lane == 0) extent[b] = m ? 64 - __clzll((long long)m) : 0;
+    __syncthreads();
+    if (wave == 0) {
+        int deg = 1, col = 0;
+        if (lane < n)
+            for (int j = 0; j < n; ++j) {
+                deg += cs[lane * 65 + j];  // row `lane`
+                col |= cs[j * 65 + lane];  // column `lane`
+            }
+        dis[lane] = (lane < n) ? 1.0f / sqrtf((float)deg) : 0.f;
+        const unsigned long long m = __ballot(deg > 1 || col != 0);
+        if (extent != nullptr && lane == 0) extent[b] = m ? 64 - __clzll((long long)m) : 0;
+    }
+    __syncthreads();
+    if (lane < n) {
+        const float dj = dis[lane];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int i = wave + 4 * t;
+            if (i < n) a[i * n + lane] = (dis[i] * (float)(cs[i * 65 + lane] + (i == lane ? 1 : 0))) * dj;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -390,17 +408,35 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     const float* o = out + b * m;
     const float* a = adj + b * n * n;
     float s = 0.f;
-    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
-        const int i = idx / n, j = idx - i * n;
-        if (j < i) continue;
-        const int k = i * n - (i * (i - 1)) / 2 + (j - i);
-        const float p = o[k], t = a[idx];
-        const float lp = fmaxf(logf(p), -100.f);
-        const float lq = fmaxf(logf(1.f - p), -100.f);
-        s += (t - 1.f) * lq - t * lp;
-        if (dlogits != nullptr) {
-            const float q = (1.f - p) * p;
-            dlogits[b * m + k] = (gscale * (p - t) / fmaxf(q, 1e-12f)) * q;
+    // Threads walk the triangle's own index k (coalesced in `out` and in the gradient); (i, j) comes from
+    // inverting k = i n - i(i-1)/2 + (j - i).  Four elements per round, their loads issued together with
+    // clamped indices (a guarded load would be a branch with a full wait behind it).
+    const float tn1 = (float)(2 * n + 1);
+    for (int k0 = threadIdx.x; k0 < m; k0 += 4 * 256) {
+        float p[4], t[4];
+        int kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + u * 256, m - 1);
+            int i = (int)((tn1 - sqrtf(tn1 * tn1 - 8.f * (float)k)) * 0.5f);
+            i = max(0, min(i, n - 1));
+            if (i * n - (i * (i - 1)) / 2 > k) --i;                    // float rounding: at most one row off
+            else if (i + 1 < n && (i + 1) * n - ((i + 1) * i) / 2 <= k) ++i;
+            const int j = i + (k - (i * n - (i * (i - 1)) / 2));
+            kk[u] = k;
+            p[u] = o[k];
+            t[u] = a[i * n + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u * 256 >= m) break;
+            const float lp = fmaxf(logf(p[u]), -100.f);
+            const float lq = fmaxf(logf(1.f - p[u]), -100.f);
+            s += (t[u] - 1.f) * lq - t[u] * lp;
+            if (dlogits != nullptr) {
+                const float q = (1.f - p[u]) * p[u];
+                dlogits[b * m + kk[u]] = (gscale * (p[u] - t[u]) / fmaxf(q, 1e-12f)) * q;
+            }
         }
     }
     const float tot = block_sum_256(s, sm);
@@ -705,7 +741,7 @@ int clear_i32(int32_t* p, int64_t count, hipStream_t s)
 int adj_normalize(int32_t* counts, int64_t B, int n, float* adj, int32_t* extent, hipStream_t s)
 {
     if (B == 0) return GTG_OK;
-    hipLaunchKernelGGL(adj_normalize_kernel, dim3((unsigned)B), dim3(64), 0, s, counts, n, adj, extent);
+    hipLaunchKernelGGL(adj_normalize_kernel, dim3((unsigned)B), dim3(256), 0, s, counts, n, adj, extent);
     return check_launch("adj_normalize_kernel");
 }
 
