@@ -366,5 +366,9 @@ class GraphVAETrainer:
         return res
 
     def edges_ok(self) -> bool:
-        """Host read-back of the adjacency and batch-gather kernels' error flags (a sync)."""
-        return int(self.err.item()) == 0 and int(self.gather_err.item()) == 0
+        """Host read-back of the adjacency and batch-gather kernels' error flags (a sync).  The adjacency
+        flag is sticky on the device (the library only ever sets it): it is cleared here once reported."""
+        bad_edges = int(self.err.item()) != 0
+        if bad_edges:
+            self.err.zero_()
+        return not bad_edges and int(self.gather_err.item()) == 0

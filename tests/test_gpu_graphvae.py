@@ -351,6 +351,28 @@ def test_loss_report_precision_recall_matches_oracle():
     assert r0.item() == 0.0 and p0.item() == 0.0
 
 
+def test_trainer_reports_a_bad_edge_once_and_recovers():
+    """An edge that leaves its graph sets the (sticky) device flag; edges_ok() reports it once, and the next
+    good batch through the same buffers is clean again -- also a check that the count scratch is left zero."""
+    from gtg_vae_amd.data import synth_graph_batch
+    from gtg_vae_amd.trainer import GraphVAETrainer
+    from oracle import graphvae_oracle as O
+
+    B, N, d, hid = 4, 10, 16, 32
+    params = O.init_params(N, d, hid, N, seed=0)
+    tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params)
+    good = synth_graph_batch(B, N, seed=5)
+    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(1))
+    want = tr.step(good.to("cuda"), eps.cuda(), kl_w=0.5, update=False)["recon"].item()
+    assert tr.edges_ok()
+    bad = synth_graph_batch(B, N, seed=5)
+    bad.edge_index = torch.cat([bad.edge_index, torch.tensor([[1], [N + 3]])], 1)  # graph 0 -> graph 1
+    tr.step(bad.to("cuda"), eps.cuda(), kl_w=0.5, update=False)
+    assert not tr.edges_ok()
+    got = tr.step(good.to("cuda"), eps.cuda(), kl_w=0.5, update=False)["recon"].item()
+    assert tr.edges_ok() and got == want
+
+
 def test_cpu_tensors_fail_loudly():
     from gtg_vae_amd import functional as Fn
     from gtg_vae_amd._lib import GtgError
