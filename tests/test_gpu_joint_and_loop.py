@@ -309,3 +309,25 @@ def test_train_loop_over_the_device_resident_dataset():
         assert tr.edges_ok()
         runs.append((tr.flat_p.clone(), [h["loss"] for h in hist]))
     assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+
+
+def test_data_parallel_step_on_gpu_equals_full_batch_oracle():
+    """Two ranks (gloo, both on this GPU) each train on half of every batch through the HIP kernels, eager and
+    graph replay, with the bucketed gradient all-reduce between the step's pieces: the parameters must follow
+    the oracle's full-batch Adam steps and stay identical on both ranks (tests/dp_gpu_worker.py)."""
+    import json
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, GTG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(here, "dp_gpu_worker.py")], env=env, capture_output=True, text=True, timeout=170)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["ranks_identical"] and out["worst_abs_param_error"] < 2e-5
