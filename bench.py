@@ -117,10 +117,16 @@ def mst_bench(device, G=65536, N=64, reps=5, cpu=True):
     ms = rep[0][5] / rep[0][4]
     bytes_per_graph = 4 * M + 4 * (2 * (N - 1) + 1)
     gbps = G * bytes_per_graph / (ms * 1e-3) / 1e9
+    traffic = None  # HBM bytes per launch from the committed PMC passes (same shape only)
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f).get("mst_triu %d %d" % (G, N), {}).get("traffic_bytes")
+    except OSError:
+        pass
     res = {"workload": "configs[3]: %d graphs, N=%d, upper-triangular fp32 rows" % (G, N),
            "graphs_per_s": G / (ms * 1e-3), "ms": ms,
            "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": gbps / PEAK_HBM_GBPS, "traffic": None,
+                        "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic,
                         "algorithmic_bytes_per_graph": bytes_per_graph}}
     if cpu:
         res["cpu_baseline"] = mst_cpu_baseline(rows_host, N)
