@@ -454,7 +454,9 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const floa
     g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
     GTG_TRY(gemm(g, s));
     // pooled[b] = max( max_{i<n_b}(A_b * T2c[b] + b2), max of the prototype rows from n_b on (+ b2) ): the
-    // epilogue reads those rows of T2c itself
+    // epilogue reads those rows of T2c itself.  Sparse per-graph kernel when d is a multiple of 4 (the adjacency
+    // rows hold 3 to 4 nonzeros), the batched dense product otherwise.
+    if ((d & 3) == 0) return pool_sparse(adj, w.t2c, meta, b2, B, n, d, pooled, argmax, s);
     g = GemmDesc();
     g.A = adj; g.lda = n; g.a_kc = true; g.strideA = (long long)n * n;
     g.B = w.t2c; g.ldb = d; g.b_kc = false; g.off_b = true;

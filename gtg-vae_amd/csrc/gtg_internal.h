@@ -166,6 +166,11 @@ int edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gold_bi
 int conv1_sparse(const float* adjc, int n, const float* W1, const float* b1, int H, const int* rows_dev, int rows_max,
                  float* h1c, hipStream_t s);
 
+// pooled (B, d) / argmax = max over the rows r < n_b of A_b T2c_b + b2, merged with the prototype rows' maximum;
+// meta as written by graph_meta; d a multiple of 4
+int pool_sparse(const float* adj, const float* t2c, const int32_t* meta, const float* b2, int64_t B, int n, int d,
+                float* pooled, int32_t* argmax, hipStream_t s);
+
 // ---- vocabulary projection + cross-entropy (proj_ce.hip) ---------------------
 // rowmap (2 R + 1 int32): [count | compact index of row r or -1 | original row of compact row i]
 int ce_rowmap(const int64_t* targets, int64_t R, int64_t padidx, int32_t* rowmap, float* loss, int32_t* pred,
