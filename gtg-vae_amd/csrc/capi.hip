@@ -610,31 +610,31 @@ int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const flo
 
     GTG_TRY(latent_bwd_elem(dz, mu, logvar, eps, kl_w_dev, kl_w, B, d, ld, dmu, dlv, s));
     const int splits = gemm_pick_splits(d, d, B, 1);
-    GemmDesc g;
+    GemmDesc g, gh;
     // dW = dY^T * h
     g.A = dmu; g.lda = ld; g.a_kc = false;
     g.B = h; g.ldb = d; g.b_kc = false;
     g.C = dWmu; g.ldc = d; g.M = d; g.N = d; g.K = B;
+    // dh = dmu * Wmu + dlogvar * Wlv
+    gh.A = dmu; gh.lda = ld; gh.a_kc = true;
+    gh.B = Wmu; gh.ldb = d; gh.b_kc = false;
+    gh.C = dh; gh.ldc = d; gh.M = B; gh.N = d; gh.K = stacked ? 2 * d : d;
     if (splits > 1) {
         g.splits = splits; g.slabs = slabs;
         GTG_TRY(gemm(g, s));
         g.A = dlv; g.C = dWlv;
         GTG_TRY(gemm(g, s));
+        GTG_TRY(gemm(gh, s));
     } else {
-        // both weight gradients in one launch
+        // both weight gradients as a batch of two, and dh beside them: one launch
         g.batch = 2; g.strideA = dlv - dmu; g.strideB = 0; g.strideC = dWlv - dWmu;
-        GTG_TRY(gemm(g, s));
+        GTG_TRY(gemm_pair(g, gh, s));
     }
-    GTG_TRY(colsum_pair(dmu, B, d, ld, dbmu, dlv, B, d, ld, dblv, cs, s));
-    // dh = dmu * Wmu + dlogvar * Wlv
-    g = GemmDesc();
-    g.A = dmu; g.lda = ld; g.a_kc = true;
-    g.B = Wmu; g.ldb = d; g.b_kc = false;
-    g.C = dh; g.ldc = d; g.M = B; g.N = d; g.K = stacked ? 2 * d : d;
-    GTG_TRY(gemm(g, s));
-    if (stacked) return GTG_OK;
-    g.A = dlv; g.B = Wlv; g.epi = EPI_ACCUM;
-    return gemm(g, s);
+    if (!stacked) {
+        gh.A = dlv; gh.B = Wlv; gh.epi = EPI_ACCUM;
+        GTG_TRY(gemm(gh, s));
+    }
+    return colsum_pair(dmu, B, d, ld, dbmu, dlv, B, d, ld, dblv, cs, s);
 }
 
 // Stand-alone reparameterisation + KL (GTVAE.reparameterize / GTVAE.loss_kl as
@@ -752,35 +752,34 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
         GTG_TRY(sigmoid_bwd(out, dout, (int64_t)B * m_out, w.dy2, s));
     else
         dy2 = dout;  // already the gradient w.r.t. the logits (gtg_bce_loss_fwd's dlogits)
-    GemmDesc g;
+    // Each weight gradient is independent of the activation gradient beside it: gemm_pair puts the two in one
+    // launch where their shapes allow.
+    GemmDesc g, ga;
     // dD2 = dy2^T * y1
     g.A = dy2; g.lda = m_out; g.a_kc = false;
     g.B = y1; g.ldb = hid; g.b_kc = false;
     g.C = dD2; g.ldc = hid; g.M = m_out; g.N = hid; g.K = B;
     g.splits = gemm_pick_splits(m_out, hid, B, 1); g.slabs = w.slabs;
-    GTG_TRY(gemm(g, s));
     // dy1 = (dy2 * D2) masked by relu
-    g = GemmDesc();
-    g.A = dy2; g.lda = m_out; g.a_kc = true;
-    g.B = D2; g.ldb = hid; g.b_kc = false;
-    g.C = w.dy1; g.ldc = hid; g.M = B; g.N = hid; g.K = m_out;
-    g.epi = EPI_MASK; g.aux = y1; g.ldaux = hid;
-    GTG_TRY(gemm(g, s));
+    ga.A = dy2; ga.lda = m_out; ga.a_kc = true;
+    ga.B = D2; ga.ldb = hid; ga.b_kc = false;
+    ga.C = w.dy1; ga.ldc = hid; ga.M = B; ga.N = hid; ga.K = m_out;
+    ga.epi = EPI_MASK; ga.aux = y1; ga.ldaux = hid;
+    GTG_TRY(gemm_pair(g, ga, s));
     // dD1 = dy1^T * z
     g = GemmDesc();
     g.A = w.dy1; g.lda = hid; g.a_kc = false;
     g.B = z; g.ldb = d; g.b_kc = false;
     g.C = dD1; g.ldc = d; g.M = hid; g.N = d; g.K = B;
     g.splits = gemm_pick_splits(hid, d, B, 1); g.slabs = w.slabs;
-    GTG_TRY(gemm(g, s));
-    // both bias gradients in one launch: dc2 = column sums of dy2, dc1 of dy1
-    GTG_TRY(colsum_pair(dy2, B, m_out, m_out, dc2, w.dy1, B, hid, hid, dc1, w.cs, s));
     // dz = dy1 * D1
-    g = GemmDesc();
-    g.A = w.dy1; g.lda = hid; g.a_kc = true;
-    g.B = D1; g.ldb = d; g.b_kc = false;
-    g.C = dz; g.ldc = d; g.M = B; g.N = d; g.K = hid;
-    return gemm(g, s);
+    ga = GemmDesc();
+    ga.A = w.dy1; ga.lda = hid; ga.a_kc = true;
+    ga.B = D1; ga.ldb = d; ga.b_kc = false;
+    ga.C = dz; ga.ldc = d; ga.M = B; ga.N = d; ga.K = hid;
+    GTG_TRY(gemm_pair(g, ga, s));
+    // both bias gradients in one launch: dc2 = column sums of dy2, dc1 of dy1
+    return colsum_pair(dy2, B, m_out, m_out, dc2, w.dy1, B, hid, hid, dc1, w.cs, s);
 }
 
 // ---------------------------------------------------------------------------

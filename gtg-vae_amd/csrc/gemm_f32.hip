@@ -338,8 +338,24 @@ struct TileB {
 // PREC selects the matrix pipe: 0 = fp32 operands (v_mfma_f32_32x32x2_f32), 1 = operands rounded to
 // bf16, 3 = the exact three-plane bf16 split with six products per k step (both on
 // v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+// LDS floats of one block: the operand double buffers of every wave group, reused by the epilogue to
+// stage the accumulators.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC, int PREC>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const KArgs a)
+constexpr int gemm_smem_floats()
+{
+    constexpr int GT = 64 * WAVES_M * WAVES_N;
+    constexpr int KS = (PREC == 3) ? 16 : BK;
+    using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, PREC == 0 ? 1 : PREC, KS>>::type;
+    using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, PREC == 0 ? 1 : PREC, KS>>::type;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int MAIN = KG * 2 * (TA::SIZE + TB::SIZE), EPI = KG * WAVES_M * WAVES_N * WTM * (WTN + 4);
+    return MAIN > EPI ? MAIN : EPI;
+}
+
+// One block's share of a GEMM launch: block `block_x` of `grid_x`, LDS at `smem` (gemm_smem_floats() floats).
+// A kernel of its own (gemm_kernel) or one of the two jobs of gemm_pair_kernel.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC, int PREC>
+__device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, const int block_x, const int grid_x)
 {
     constexpr int GT = 64 * WAVES_M * WAVES_N;  // threads of one wave group
     constexpr int GW = WAVES_M * WAVES_N;
@@ -354,8 +370,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
     // operand double buffers per wave group; reused by the epilogue to stage the accumulators
     constexpr int LDC = WTN + 4;
     constexpr int SMEM_GROUP = 2 * (TA::SIZE + TB::SIZE);
-    constexpr int SMEM_MAIN = KG * SMEM_GROUP, SMEM_EPI = KG * GW * WTM * LDC;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
 
     const int kg = (KG > 1) ? (int)threadIdx.x / GT : 0;
     const int tid = (KG > 1) ? (int)threadIdx.x % GT : (int)threadIdx.x;
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
     // work.  The launch is sized for the static M; blocks past the live tile
     // count leave at once, and the live ones (block ids 0..live-1, dealt evenly
     // over the XCDs) are remapped among themselves.
-    int live = gridDim.x;
+    int live = grid_x;
     int tiles_m = a.tiles_m;
     if (a.m_dev) {
         tiles_m = (Mr + BM - 1) / BM;
@@ -395,19 +409,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
         int s = tail > 0 ? slots / tail : 1;
         s = min(s, nk_all / 4);  // a part keeps at least four k steps
         s = max(s, 1);
-        if ((int)blockIdx.x >= full + tail * s) return;
-        if ((int)blockIdx.x < full) {
-            bid = xcd_remap(blockIdx.x, full);
+        if (block_x >= full + tail * s) return;
+        if (block_x < full) {
+            bid = xcd_remap(block_x, full);
         } else {
-            const int u = xcd_remap(blockIdx.x - full, tail * s);  // the parts of a tile share an XCD
+            const int u = xcd_remap(block_x - full, tail * s);  // the parts of a tile share an XCD
             tail_tile = u / s;
             part = u % s;
             parts = s;
             bid = full + tail_tile;
         }
     } else {
-        if ((int)blockIdx.x >= live) return;
-        bid = xcd_remap(blockIdx.x, live);
+        if (block_x >= live) return;
+        bid = xcd_remap(block_x, live);
     }
     const int tn = bid % a.tiles_n;
     bid /= a.tiles_n;
@@ -903,6 +917,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const
     }
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC, int PREC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const KArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, WAVES_M, WAVES_N, KG, AKC, BKC, PREC>()];
+    gemm_body<BM, BN, WAVES_M, WAVES_N, KG, AKC, BKC, PREC>(a, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two independent batch-sized GEMMs in one launch: blocks [0, n0) run job 0, the rest job 1.  Such GEMMs
+// are latency-bound (a block's few k steps, prologue and epilogue; their duration hardly moves when the
+// tile count doubles), so two that do not depend on each other cost little more than one, and a kernel
+// boundary is saved besides.  Each job is computed exactly as by a launch of its own.
+template <int BM_, int BN_, int WM_, int WN_, int KG_, bool AKC_, bool BKC_>
+struct GemmJob {
+    static constexpr int THREADS = 64 * WM_ * WN_ * KG_;
+    static constexpr int SMEM = gemm_smem_floats<BM_, BN_, WM_, WN_, KG_, AKC_, BKC_, 0>();
+    static __device__ __forceinline__ void run(const KArgs& a, float* smem, int block_x, int grid_x)
+    {
+        gemm_body<BM_, BN_, WM_, WN_, KG_, AKC_, BKC_, 0>(a, smem, block_x, grid_x);
+    }
+};
+
+template <class J0, class J1>
+__global__ __launch_bounds__(J0::THREADS) void gemm_pair_kernel(const KArgs a0, const KArgs a1, const int n0)
+{
+    static_assert(J0::THREADS == J1::THREADS, "the jobs of a pair share the block size");
+    __shared__ __attribute__((aligned(16))) float smem[J0::SMEM > J1::SMEM ? J0::SMEM : J1::SMEM];
+    if ((int)blockIdx.x < n0)
+        J0::run(a0, smem, (int)blockIdx.x, n0);
+    else
+        J1::run(a1, smem, (int)blockIdx.x - n0, (int)gridDim.x - n0);
+}
+
 // C (+)= sum over slabs, in slab order.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long mn,
                                                             int N, float* __restrict__ C, int ldc, int accumulate)
@@ -1001,10 +1047,23 @@ size_t gemm_splitk_workspace(int M, int N, int K, int batch)
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
-int gemm(const GemmDesc& d, hipStream_t s)
+namespace {
+
+// A validated launch: kernel arguments, tile configuration and grid of one GemmDesc.
+struct GemmPlan {
+    KArgs k;
+    TileCfg cfg;
+    long long grid;
+    int splits;
+    bool empty;  // nothing to compute
+};
+
+int gemm_plan(const GemmDesc& d, GemmPlan& p)
 {
+    p.empty = true;
     if (d.M < 0 || d.N < 0 || d.K < 0 || d.batch < 0) return set_error(GTG_ERR_INVALID, "gemm: negative dimension");
     if (d.M == 0 || d.N == 0 || d.batch == 0) return GTG_OK;
+    p.empty = false;
     if (!d.A || !d.B) return set_error(GTG_ERR_INVALID, "gemm: null operand");
     if (d.epi == EPI_POOL) {
         if (d.M > 64 || !d.pool_val || !d.pool_idx)
@@ -1018,7 +1077,7 @@ int gemm(const GemmDesc& d, hipStream_t s)
     int bm, bn;
     cfg_dims(cfg, bm, bn);
 
-    KArgs k;
+    KArgs& k = p.k;
     k.A = d.A;
     k.B = d.B;
     k.C = d.C;
@@ -1091,6 +1150,23 @@ int gemm(const GemmDesc& d, hipStream_t s)
         grid += k.tail_slots;  // the split tail adds fewer than tail_slots blocks
     }
     if (grid > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "gemm: grid too large");
+    p.cfg = cfg;
+    p.grid = grid;
+    p.splits = splits;
+    return GTG_OK;
+}
+
+}  // namespace
+
+int gemm(const GemmDesc& d, hipStream_t s)
+{
+    GemmPlan p;
+    if (int rc = gemm_plan(d, p)) return rc;
+    if (p.empty) return GTG_OK;
+    const KArgs& k = p.k;
+    const TileCfg cfg = p.cfg;
+    const long long grid = p.grid;
+    const int splits = p.splits;
 
     static const char* const kNames[CFG_COUNT][3] = {
         {"gemm128_nt", "gemm128_nn", "gemm128_tn"},
@@ -1130,6 +1206,29 @@ int gemm(const GemmDesc& d, hipStream_t s)
         return check_launch("splitk_reduce_kernel");
     }
     return GTG_OK;
+}
+
+int gemm_pair(const GemmDesc& d0, const GemmDesc& d1, hipStream_t s)
+{
+    GemmPlan p0, p1;
+    if (int rc = gemm_plan(d0, p0)) return rc;
+    if (int rc = gemm_plan(d1, p1)) return rc;
+    const bool plain = !p0.empty && !p1.empty && p0.splits == 1 && p1.splits == 1 && p0.k.tail_ws == nullptr &&
+                       p1.k.tail_ws == nullptr && p0.grid + p1.grid <= 0x7fffffffLL;
+    const bool tn0 = !d0.a_kc && !d0.b_kc, nn1 = d1.a_kc && !d1.b_kc;
+    static const bool pair_off = getenv("GTG_GEMM_PAIR") && atoi(getenv("GTG_GEMM_PAIR")) == 0;  // experiment hook
+    // A 64x64 job beside a 32x32 one (the latter over eight wave groups to share the block size) measured
+    // slower than the two launches: its LDS leaves one block per CU.
+    if (!(plain && !pair_off && tn0 && nn1 && p0.cfg == CFG_32_K4 && p1.cfg == CFG_32_K4)) {
+        if (int rc = gemm(d0, s)) return rc;
+        return gemm(d1, s);
+    }
+    ProfScope prof(s, "gemm_pair32k4_tn+nn", (long long)d0.M * d0.batch, d0.N, d0.K);
+    using J0 = GemmJob<32, 32, 1, 1, 4, false, false>;
+    using J1 = GemmJob<32, 32, 1, 1, 4, true, false>;
+    hipLaunchKernelGGL((gemm_pair_kernel<J0, J1>), dim3((unsigned)(p0.grid + p1.grid)), dim3(J0::THREADS), 0, s, p0.k,
+                       p1.k, (int)p0.grid);
+    return check_launch("gemm_pair_kernel");
 }
 
 }  // namespace gtg

@@ -100,6 +100,9 @@ void gemm_tail_workspace(size_t* ws_bytes, size_t* counter_bytes);
 size_t gemm_splitk_workspace(int M, int N, int K, int batch);
 int gemm_pick_splits(int M, int N, int K, int batch);
 int gemm(const GemmDesc& d, hipStream_t s);
+// Two independent GEMMs; one launch when both run on the 32x32 K-group tile configuration (d0 transposed-A x
+// plain-B, d1 plain-A x plain-B), otherwise one after the other.  Results equal gemm(d0), gemm(d1) bit for bit.
+int gemm_pair(const GemmDesc& d0, const GemmDesc& d1, hipStream_t s);
 
 // ---- element-wise / reduction kernels (graph_ops.hip) -----------------------
 int adj_count(const int64_t* edge_index, int64_t E, int64_t B, int n, int32_t* counts, int32_t* err, hipStream_t s);
