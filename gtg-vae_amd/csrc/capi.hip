@@ -483,7 +483,8 @@ static void enc_cbwd_layout(Carver& c, int64_t B, int n, int d, EncCBwdWs* w)
     w->cs = reinterpret_cast<float*>(c.take<char>(max2(max2(colsum_workspace(B, d), colsum_workspace((int64_t)rows, H)),
                                                        (size_t)gemm_colsum_rows((int)rows) * H * sizeof(float))));
     w->slabs = reinterpret_cast<float*>(
-        c.take<char>(max2(gemm_splitk_workspace(d, H, (int)rows, 1), gemm_splitk_workspace(H, n, (int)rows, 1))));
+        c.take<char>(max2(max2(gemm_splitk_workspace(d, H, (int)rows, 1), gemm_splitk_workspace(H, n, (int)rows, 1)),
+                          dw2_sparse_applies(B, n, d, H) ? dw2_sparse_workspace(d, H) : 0)));
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);
     w->tail = reinterpret_cast<float*>(c.take<char>(tb));
@@ -520,12 +521,18 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, w.tail_cnt, (int)w.tail_cnt_count, s));
     GTG_TRY(proto_grad(dpooled, argmax, meta, B, n, d, w.pg, w.dT2c, s));
     GemmDesc g;
-    // dW2 = dT2c^T * H1c
-    g.A = w.dT2c; g.lda = d; g.a_kc = false;
-    g.B = h1c; g.ldb = H; g.b_kc = false;
-    g.C = dW2; g.ldc = H; g.M = d; g.N = H; g.K = rows; g.k_dev = all_rows;
-    g.splits = gemm_pick_splits(d, H, rows, 1); g.slabs = w.slabs;
-    GTG_TRY(gemm(g, s));
+    // dW2 = dT2c^T * H1c: from the pooled gradient and the winning rows where the shape allows (one aggregated
+    // row of H1c per graph and pooled column), else as the dense product
+    static const bool dw2_dense = getenv("GTG_DW2_DENSE") && atoi(getenv("GTG_DW2_DENSE")) != 0;  // experiment hook
+    if (!dw2_dense && dw2_sparse_applies(B, n, d, H)) {
+        GTG_TRY(dw2_sparse(adj, h1c, H, dpooled, argmax, meta, w.dT2c, B, n, d, w.slabs, dW2, s));
+    } else {
+        g.A = w.dT2c; g.lda = d; g.a_kc = false;
+        g.B = h1c; g.ldb = H; g.b_kc = false;
+        g.C = dW2; g.ldc = H; g.M = d; g.N = H; g.K = rows; g.k_dev = all_rows;
+        g.splits = gemm_pick_splits(d, H, rows, 1); g.slabs = w.slabs;
+        GTG_TRY(gemm(g, s));
+    }
     // dZ1c = (dT2c * W2) masked by relu
     g = GemmDesc();
     g.A = w.dT2c; g.lda = d; g.a_kc = true;

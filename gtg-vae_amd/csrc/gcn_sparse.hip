@@ -1,6 +1,7 @@
 // The two propagate steps of the encoder as sparse row products (gfx950): the first GCN layer on identity node
 // features, GCNConv's propagate + bias + ReLU at /root/reference/src/graph_vae.py:107-108 (conv1, relu) for
-// x = I_n, and conv2's propagate + bias fused with global_max_pool (graph_vae.py:110, :25).
+// x = I_n, and conv2's propagate + bias fused with global_max_pool (graph_vae.py:110, :25); and the gradient
+// of conv2's weight taken through that max-pool's one-winner-per-column routing (autograd of the same lines).
 //
 // With identity features conv1 is H1 = relu(A W1^T + b1) where A is the
 // normalised adjacency: an AMR graph's row of A has deg + 1 nonzeros (3 to 4 on
@@ -227,6 +228,182 @@ __global__ __launch_bounds__(256) void pool_sparse_kernel(const float* __restric
     argmax[(long long)b * d + c] = bidx;
 }
 
+// ---------------------------------------------------------------------------
+// dW2 through the max-pool's sparsity.  T2 = H1 W2^T is aggregated and max-pooled, so the gradient that reaches
+// W2 is dW2[c, :] = sum_b g[b, c] * Y_b[am_b(c), :], where g = dpooled, am = the winning row and
+// Y_b = A_b H1_b is the aggregated hidden block of graph b (a prototype row aggregates to itself): one row of
+// 2d numbers per graph and pooled column instead of the dense (rows x d)^T (rows x 2d) product, 1/n_b of
+// its multiply-adds.  A block owns 64 columns of H1c and up to 512 pooled columns c and walks every G-th
+// graph: it stages the graph's rows of the slab in LDS, aggregates them sparsely (lane k holds A_b[i, k],
+// ballot, v_readlane coefficient, one LDS read per nonzero), then every lane -- one pooled column c each --
+// adds g * Y[am, 0..63] to its 64 accumulators (LDS row stride 65: lanes on different rows read different
+// banks, lanes on the same row share a broadcast).  Two graphs are in flight in registers (rows, adjacency
+// rows, g and am): the loads of graph t + 2 are issued before graph t is accumulated.  The columns won by a prototype row
+// arrive as n more items: row i of the prototype block of dT2c (the sum of g over the graphs whose maximum
+// row i won) times prototype row i of H1c.  Each group of graphs leaves a partial dW2, stored transposed (c along
+// the lanes: whole 256-byte runs); dw2_reduce_kernel adds the groups in order and transposes back: reproducible.
+constexpr int DW_THREADS = 512;
+constexpr int DW_COLS = 64;
+constexpr int DW_LD = 65;
+constexpr int DW_CPB = 512;   // pooled columns per block: 64 per wave
+constexpr int DW_GROUPS = 16;
+
+__global__ __launch_bounds__(DW_THREADS) void dw2_sparse_kernel(const float* __restrict__ adj, const float* __restrict__ h1c,
+                                                                int ldh, const float* __restrict__ dpool,
+                                                                const int32_t* __restrict__ argmax,
+                                                                const int32_t* __restrict__ meta,
+                                                                const float* __restrict__ dT2c, int B, int n, int d,
+                                                                float* __restrict__ partial)
+{
+    __shared__ float Hs[64 * DW_LD];
+    __shared__ float Y[2][64 * DW_LD];  // alternate between items: one is accumulated from while the next is built
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in a scalar register: row indices stay scalar
+    const float* const hcol = h1c + blockIdx.x * DW_COLS + lane;  // this lane's column of H1c while staging
+    const int G = gridDim.y, gr = blockIdx.y;
+    const int c = blockIdx.z * DW_CPB + tid;      // this lane's pooled column while accumulating
+    const bool c_ok = c < d;
+    const int cc = min(c, d - 1);
+    const bool wave_live = blockIdx.z * DW_CPB + wave * 64 < d;  // wave-uniform
+    const int R = meta[2 * B];
+    const int ng = gr < B ? (B - gr + G - 1) / G : 0;  // graphs gr, gr + G, ...
+    const int np = gr < n ? (n - gr + G - 1) / G : 0;  // prototype rows gr, gr + G, ...
+    const int items = ng + np;
+
+    for (int i = tid; i < 64 * DW_LD; i += DW_THREADS) {
+        Hs[i] = 0.f;  // rows past a graph's extent are read with a zero coefficient: keep them finite
+        Y[0][i] = 0.f;
+        Y[1][i] = 0.f;
+    }
+    float acc[DW_COLS];
+#pragma unroll
+    for (int k = 0; k < DW_COLS; ++k) acc[k] = 0.f;
+
+    // Two items are in flight in registers: the loads of item t + 2 are issued while item t is accumulated
+    // and have the whole of item t + 1 to land.
+    struct Item {
+        float row[8], a[8], g;
+        int am, nb;  // nb < 0: a prototype row
+    };
+    // Per item (this block's graphs, then its prototype rows), item t in lane t: extent (-1 marks a prototype
+    // row), first stored row, and the row of the (B x d) arrays that holds its g.  A fetch then starts its loads
+    // at once, and it is the same straight-line code for both kinds of item: with a branch around the loads the
+    // compiler drains every outstanding load at the top of the loop, which undoes the prefetch.  (At most 64
+    // items per group: checked on the host.)
+    int nbv = -1, offv = 0;
+    if (lane < ng) {
+        nbv = meta[gr + G * lane];
+        offv = meta[B + gr + G * lane];
+    } else if (lane < items) {
+        offv = R + gr + G * (lane - ng);
+    }
+    auto fetch = [&](Item& p, int it_raw) {
+        const int it = min(it_raw, items - 1);  // past the end: a harmless repeat of the last item
+        const int nb = __builtin_amdgcn_readlane(nbv, it), off = __builtin_amdgcn_readlane(offv, it);
+        const bool proto = nb < 0;
+        const int b = proto ? 0 : gr + G * it;
+        const int k_last = max(nb - 1, 0);
+        const float* A = adj + (long long)b * n * n + min(lane, n - 1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j = wave + 8 * t;
+            p.row[t] = hcol[(off + min(j, k_last)) * ldh];  // scalar row offset, 32 bits (checked on the host)
+            p.a[t] = keep_if(A[min(j, n - 1) * n], j < nb && lane < nb);
+        }
+        const int am = argmax[(long long)b * d + cc];
+        const float* gsrc = proto ? dT2c + (long long)off * d : dpool + (long long)b * d;
+        const bool real = proto || (am >= 0 && am < nb);
+        p.g = keep_if(gsrc[cc], c_ok && real);
+        p.am = proto ? off - R : (real ? am : 0);
+        p.nb = nb;
+    };
+    auto process = [&](Item& p, int it) {
+        const int nb = p.nb;
+        const bool proto = nb < 0;  // block-uniform
+        float* const Yc = Y[it & 1];
+        if (!proto) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = wave + 8 * t;
+                if (j < nb) Hs[j * DW_LD + lane] = p.row[t];
+            }
+        } else if (wave == 0) {
+            Yc[p.am * DW_LD + lane] = p.row[0];
+        }
+        __syncthreads();
+        if (!proto) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int i = wave + 8 * t;
+                if (i >= nb) break;  // wave-uniform
+                unsigned long long mask = __ballot(p.a[t] != 0.f);
+                float y = 0.f;
+                while (mask) {
+                    const int k = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.a[t]), k));
+                    y = fmaf(ak, Hs[k * DW_LD + lane], y);
+                }
+                Yc[i * DW_LD + lane] = y;
+            }
+        }
+        __syncthreads();  // Y complete; Hs free for the next item
+        const float g = p.g;
+        const float* yrow = Yc + p.am * DW_LD;
+        fetch(p, it + 2);
+        if (wave_live) {
+#pragma unroll
+            for (int k = 0; k < DW_COLS; ++k) acc[k] = fmaf(g, yrow[k], acc[k]);
+        }
+    };
+    Item p0, p1;
+    if (items > 0) {
+        fetch(p0, 0);
+        fetch(p1, 1);
+    }
+    __syncthreads();  // LDS cleared
+    for (int it = 0; it < items; it += 2) {
+        process(p0, it);
+        if (it + 1 < items) process(p1, it + 1);
+    }
+    // partial[group][column of H1c][c]: c runs along the lanes, so every store instruction is one 256-byte run
+    if (c_ok) {
+        float* dst = partial + ((long long)gr * ldh + blockIdx.x * DW_COLS) * d + c;
+#pragma unroll
+        for (int k = 0; k < DW_COLS; ++k) dst[(long long)k * d] = acc[k];
+    }
+}
+
+// dW2[c][h] = sum over groups of partial[group][h][c], groups in order; 32 x 32 tiles transposed through LDS so
+// that reads and writes are both whole 128-byte rows.
+__global__ __launch_bounds__(256) void dw2_reduce_kernel(const float* __restrict__ partial, int d, int H,
+                                                         float* __restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
+    const long long plane = (long long)H * d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int h = h0 + ty + 8 * i, c = c0 + tx;
+        // all groups' loads in flight at once (clamped indices: H is a multiple of 32, d need not be)
+        const float* src = partial + (long long)min(h, H - 1) * d + min(c, d - 1);
+        float v[DW_GROUPS];
+#pragma unroll
+        for (int g = 0; g < DW_GROUPS; ++g) v[g] = src[g * plane];
+        float sum = v[0];
+#pragma unroll
+        for (int g = 1; g < DW_GROUPS; ++g) sum += v[g];
+        tile[ty + 8 * i][tx] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, h = h0 + tx;
+        if (c < d && h < H) out[(long long)c * H + h] = tile[tx][ty + 8 * i];
+    }
+}
+
 }  // namespace
 
 int conv1_sparse(const float* adjc, int n, const float* W1, const float* b1, int H, const int* rows_dev, int rows_max,
@@ -251,6 +428,29 @@ int pool_sparse(const float* adj, const float* t2c, const int32_t* meta, const f
     hipLaunchKernelGGL(pool_sparse_kernel, dim3((d + PS_COLS - 1) / PS_COLS, (unsigned)B), dim3(256), 0, s, adj, t2c, meta,
                        b2, (int)B, n, d, pooled, argmax);
     return check_launch("pool_sparse_kernel");
+}
+
+bool dw2_sparse_applies(int64_t B, int n, int d, int H)
+{
+    // small batches are launch-bound either way and keep the dense product
+    return n >= 1 && n <= 64 && (H % DW_COLS) == 0 && B * (int64_t)d >= 65536 && (B + DW_GROUPS - 1) / DW_GROUPS + (n + DW_GROUPS - 1) / DW_GROUPS <= 64 &&
+           (B * n + n) * (int64_t)H < (1ll << 31);
+}
+
+size_t dw2_sparse_workspace(int d, int H) { return (size_t)DW_GROUPS * d * H * sizeof(float); }
+
+int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, const int32_t* argmax, const int32_t* meta,
+               const float* dT2c, int64_t B, int n, int d, float* partial, float* dW2, hipStream_t s)
+{
+    if (!dw2_sparse_applies(B, n, d, H)) return set_error(GTG_ERR_INVALID, "dw2_sparse: shape not supported");
+    if ((reinterpret_cast<uintptr_t>(partial) & 15) != 0 || (reinterpret_cast<uintptr_t>(dW2) & 15) != 0)
+        return set_error(GTG_ERR_INVALID, "dw2_sparse: outputs must be 16-byte aligned");
+    ProfScope prof(s, "dw2_sparse", B * n, H, d);
+    hipLaunchKernelGGL(dw2_sparse_kernel, dim3(H / DW_COLS, DW_GROUPS, (d + DW_CPB - 1) / DW_CPB), dim3(DW_THREADS), 0, s,
+                       adj, h1c, H, dpool, argmax, meta, dT2c, (int)B, n, d, partial);
+    if (int rc = check_launch("dw2_sparse_kernel")) return rc;
+    hipLaunchKernelGGL(dw2_reduce_kernel, dim3((d + 31) / 32, (H + 31) / 32), dim3(256), 0, s, partial, d, H, dW2);
+    return check_launch("dw2_reduce_kernel");
 }
 
 }  // namespace gtg

@@ -171,6 +171,12 @@ int conv1_sparse(const float* adjc, int n, const float* W1, const float* b1, int
 
 // pooled (B, d) / argmax = max over the rows r < n_b of A_b T2c_b + b2, merged with the prototype rows' maximum;
 // meta as written by graph_meta; d a multiple of 4
+// dW2 = dT2c^T * H1c computed from the pooled gradient and the arg-max rows instead of the dense product
+// (gcn_sparse.hip); dT2c supplies only its prototype rows.  partial: dw2_sparse_workspace() bytes.
+bool dw2_sparse_applies(int64_t B, int n, int d, int H);
+size_t dw2_sparse_workspace(int d, int H);
+int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, const int32_t* argmax, const int32_t* meta,
+               const float* dT2c, int64_t B, int n, int d, float* partial, float* dW2, hipStream_t s);
 int pool_sparse(const float* adj, const float* t2c, const int32_t* meta, const float* b2, int64_t B, int n, int d,
                 float* pooled, int32_t* argmax, hipStream_t s);
 
