@@ -151,6 +151,53 @@ def test_compact_encoder_edge_cases(N, d):
     assert _relerr(outs[0][0], outs[1][0]) < 1e-6
 
 
+@pytest.mark.parametrize("B,N,d", [(130, 64, 512), (300, 10, 256), (256, 33, 288)])
+def test_conv2_weight_gradient_through_the_pool_routing(B, N, d):
+    """At B*d >= 65536 the compact backward takes dW2 from the pooled gradient and the winning rows
+    (one aggregated row of H1 per graph and column) instead of the dense product: awkward graphs
+    cycled through the batch (empty, one edge, high indices only, chain, self loops, multi-edges,
+    complete, random), a batch that is not a multiple of the 16 graph groups, a width whose last
+    wave of pooled columns is partly idle (288); all four gradients against the oracle."""
+    from gtg_vae_amd import functional as Fn
+    from oracle import graphvae_oracle as O
+
+    rng = np.random.default_rng(B + N + d)
+    edges = []
+    for b in range(B):
+        o, kind = b * N, b % 8
+        if kind == 1:
+            edges += [(o, o + 1)]
+        elif kind == 2:
+            edges += [(o + N - 3, o + N - 1), (o + N - 1, o + N - 3)]
+        elif kind == 3:
+            edges += [(o + i, o + i + 1) for i in range(N - 1)] + [(o + i + 1, o + i) for i in range(N - 1)]
+        elif kind == 4:
+            edges += [(o + 2, o + 2), (o, o)]
+        elif kind == 5:
+            edges += [(o, o + 4)] * 3 + [(o + 4, o)]
+        elif kind == 6:
+            m = min(N, 9)
+            edges += [(o + i, o + j) for i in range(m) for j in range(m) if i != j]
+        elif kind == 7:
+            m = int(rng.integers(2, N + 1))
+            for _ in range(2 * m):
+                i, j = rng.integers(0, m, size=2)
+                edges += [(o + int(i), o + int(j))]
+    ei = torch.tensor(edges, dtype=torch.long).t().contiguous()
+    p = {k: v.clone().requires_grad_(True) for k, v in _oracle_params(N, d, 16, seed=5).items()}
+    want = O.encode(p, None, ei, B, N)
+    up = torch.randn(B, d, generator=torch.Generator().manual_seed(6))
+    (want * up).sum().backward()
+    names = ["encoder.conv1.lin.weight", "encoder.conv1.bias", "encoder.conv2.lin.weight", "encoder.conv2.bias"]
+    gp = [p[k].detach().cuda().requires_grad_(True) for k in names]
+    adj, extents = Fn.build_adj(ei.cuda(), B, N, return_extents=True)
+    got, _ = Fn.EncoderFn.apply(adj, None, *gp, extents)
+    assert _relerr(got, want) < 1e-5
+    (got * up.cuda()).sum().backward()
+    for k, t in zip(names, gp):
+        assert _relerr(t.grad, p[k].grad) < 1e-4, k
+
+
 @pytest.mark.parametrize("N,d", [(7, 6), (64, 130), (33, 5)])
 def test_compact_encoder_on_dense_graphs_and_odd_widths(N, d):
     """First layer as sparse row products: complete graphs (every adjacency entry nonzero), a hidden
