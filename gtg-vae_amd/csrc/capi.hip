@@ -518,8 +518,7 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     const int32_t* all_rows = meta + 2 * B + 1;  // R + n
 
     // dT2c: real rows from the max-pool routing, prototype rows from the graphs whose maximum they won
-    GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, w.tail_cnt, (int)w.tail_cnt_count, s));
-    GTG_TRY(proto_grad(dpooled, argmax, meta, B, n, d, w.pg, w.dT2c, s));
+    GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, w.pg, w.tail_cnt, (int)w.tail_cnt_count, s));
     GemmDesc g;
     // dW2 = dT2c^T * H1c: from the pooled gradient and the winning rows where the shape allows (one aggregated
     // row of H1c per graph and pooled column), else as the dense product

@@ -515,52 +515,22 @@ __global__ __launch_bounds__(256) void adj_compact_kernel(const float* __restric
     for (int idx = threadIdx.x; idx < nb * n; idx += 256) dst[idx] = src[idx];
 }
 
-// max-pool backward for compact rows: dT2c[off_b + j, c] = adj[b, am, j] * dpool[b,c], j < n_b
-// (zero when the winning row am is a prototype row: it has no edge to a stored row)
-__global__ __launch_bounds__(256) void pool_bwd_gather_compact_kernel(const float* __restrict__ adj,
-                                                                      const float* __restrict__ dpool,
-                                                                      const int32_t* __restrict__ argmax,
-                                                                      const int32_t* __restrict__ meta, int64_t B,
-                                                                      int n, int d, float* __restrict__ dT2,
-                                                                      int32_t* __restrict__ zero, int zero_count)
-{
-    // the graph's adjacency block sits in LDS, one padded row per winning-row lookup
-    __shared__ float sadj[64 * 65];
-    const int64_t b = blockIdx.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    // also clears the arrival counters of the GEMM that follows (one launch less than a separate clear)
-    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_count; i += gridDim.x * gridDim.y * 256)
-        zero[i] = 0;
-    const int nb = meta[b], off = meta[B + b];
-    const float* src = adj + b * n * n;
-    for (int idx = threadIdx.x; idx < nb * n; idx += 256) sadj[(idx / n) * 65 + (idx % n)] = src[idx];
-    __syncthreads();
-    if (c >= d) return;
-    const float g = dpool[b * d + c];
-    const int am = argmax[b * d + c];
-    // a prototype row that won the maximum has no edge to a stored row
-    const float scale = (am < nb) ? g : 0.f;
-    const float* arow = sadj + (am < nb ? am : 0) * 65;
-    float* out = dT2 + (int64_t)off * d + c;
-#pragma unroll 4
-    for (int j = 0; j < nb; ++j) out[(int64_t)j * d] = arow[j] * scale;
-}
-
 // gradient reaching the prototype rows: dQ[i][c] = sum over graphs whose pooled
-// maximum in column c is row i >= n_b.  Stage 1: block (64 columns, one segment
+// maximum in column c is row i >= n_b.  Stage 1: a wave (64 columns, one segment
 // of the batch) walks its graphs in order, each thread adding into its own
 // column of an LDS (n x 64) table; stage 2 adds the segments in order and
-// writes the rows at offset R of dT2c.  Ordered: reproducible.
+// writes the rows at offset R of dT2c.  Ordered: reproducible.  Stage 1 rides in
+// the launch of pool_bwd_gather_compact_kernel (its first blocks): one kernel boundary less.
 constexpr int PG_SEG = 32;
-__global__ __launch_bounds__(64) void proto_grad_stage1(const float* __restrict__ dpool,
+__device__ __forceinline__ void proto_grad_stage1_block(float* __restrict__ tab, int cb, int seg,
+                                                        const float* __restrict__ dpool,
                                                         const int32_t* __restrict__ argmax,
                                                         const int32_t* __restrict__ meta, int64_t B, int n, int d,
                                                         float* __restrict__ partial)
 {
-    __shared__ float tab[64 * 64];
     const int tc = threadIdx.x;
-    const int c = blockIdx.x * 64 + tc;
-    const int seg = blockIdx.y;
+    if (tc >= 64) return;
+    const int c = cb * 64 + tc;
     for (int i = 0; i < n; ++i) tab[i * 64 + tc] = 0.f;
     const int64_t per = (B + PG_SEG - 1) / PG_SEG;
     const int64_t b0 = seg * per, b1 = min(B, b0 + per);
@@ -582,6 +552,45 @@ __global__ __launch_bounds__(64) void proto_grad_stage1(const float* __restrict_
         }
         for (int i = 0; i < n; ++i) partial[((int64_t)seg * n + i) * d + c] = tab[i * 64 + tc];
     }
+}
+
+// max-pool backward for compact rows: dT2c[off_b + j, c] = adj[b, am, j] * dpool[b,c], j < n_b
+// (zero when the winning row am is a prototype row: it has no edge to a stored row)
+__global__ __launch_bounds__(256) void pool_bwd_gather_compact_kernel(const float* __restrict__ adj,
+                                                                      const float* __restrict__ dpool,
+                                                                      const int32_t* __restrict__ argmax,
+                                                                      const int32_t* __restrict__ meta, int64_t B,
+                                                                      int n, int d, float* __restrict__ dT2,
+                                                                      int32_t* __restrict__ zero, int zero_count,
+                                                                      float* __restrict__ pg_partial, int pg_rows)
+{
+    // the graph's adjacency block sits in LDS, one padded row per winning-row lookup
+    __shared__ float sadj[64 * 65];
+    // the first pg_rows rows of the grid are the prototype-gradient stage-1 blocks (they run longest: first out)
+    if ((int)blockIdx.y < pg_rows) {
+        const int q = blockIdx.y * gridDim.x + blockIdx.x, ncb = (d + 63) / 64;
+        if (q < ncb * PG_SEG) proto_grad_stage1_block(sadj, q % ncb, q / ncb, dpool, argmax, meta, B, n, d, pg_partial);
+        return;
+    }
+    const int64_t b = blockIdx.y - pg_rows;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // also clears the arrival counters of the GEMM that follows (one launch less than a separate clear)
+    for (int i = ((blockIdx.y - pg_rows) * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_count;
+         i += gridDim.x * (gridDim.y - pg_rows) * 256)
+        zero[i] = 0;
+    const int nb = meta[b], off = meta[B + b];
+    const float* src = adj + b * n * n;
+    for (int idx = threadIdx.x; idx < nb * n; idx += 256) sadj[(idx / n) * 65 + (idx % n)] = src[idx];
+    __syncthreads();
+    if (c >= d) return;
+    const float g = dpool[b * d + c];
+    const int am = argmax[b * d + c];
+    // a prototype row that won the maximum has no edge to a stored row
+    const float scale = (am < nb) ? g : 0.f;
+    const float* arow = sadj + (am < nb ? am : 0) * 65;
+    float* out = dT2 + (int64_t)off * d + c;
+#pragma unroll 4
+    for (int j = 0; j < nb; ++j) out[(int64_t)j * d] = arow[j] * scale;
 }
 
 __global__ __launch_bounds__(256) void proto_grad_stage2(const float* __restrict__ partial,
@@ -904,25 +913,20 @@ int graph_meta(const int32_t* extent, const float* adj, int64_t B, int n, int32_
     return check_launch("adj_compact_kernel");
 }
 
-int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,
-                            int64_t B, int n, int d, float* dT2, int32_t* zero, int zero_count, hipStream_t s)
-{
-    if (B == 0 || d == 0) return clear_i32(zero, zero_count, s);
-    hipLaunchKernelGGL(pool_bwd_gather_compact_kernel, dim3((d + 255) / 256, (unsigned)B), dim3(256), 0, s, adj, dpool,
-                       argmax, meta, B, n, d, dT2, zero, zero_count);
-    return check_launch("pool_bwd_gather_compact_kernel");
-}
-
 size_t proto_grad_workspace(int n, int d) { return (size_t)PG_SEG * n * d * sizeof(float); }
 
-int proto_grad(const float* dpool, const int32_t* argmax, const int32_t* meta, int64_t B, int n, int d, float* partial,
-               float* dT2c, hipStream_t s)
+// dT2c, real rows and prototype rows: the gather and stage 1 of the prototype gradient in one launch, then stage 2.
+int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,
+                            int64_t B, int n, int d, float* dT2, float* pg_partial, int32_t* zero, int zero_count,
+                            hipStream_t s)
 {
-    hipLaunchKernelGGL(proto_grad_stage1, dim3((d + 63) / 64, PG_SEG), dim3(64), 0, s, dpool, argmax, meta, B, n, d,
-                       partial);
-    int rc = check_launch("proto_grad_stage1");
-    if (rc) return rc;
-    hipLaunchKernelGGL(proto_grad_stage2, dim3((n * d + 255) / 256), dim3(256), 0, s, partial, meta + 2 * B, n, d, dT2c);
+    if (B == 0 || d == 0) return clear_i32(zero, zero_count, s);
+    const int gx = (d + 255) / 256;
+    const int pg_rows = (((d + 63) / 64) * PG_SEG + gx - 1) / gx;
+    hipLaunchKernelGGL(pool_bwd_gather_compact_kernel, dim3(gx, (unsigned)(B + pg_rows)), dim3(256), 0, s, adj, dpool,
+                       argmax, meta, B, n, d, dT2, zero, zero_count, pg_partial, pg_rows);
+    if (int rc = check_launch("pool_bwd_gather_compact_kernel")) return rc;
+    hipLaunchKernelGGL(proto_grad_stage2, dim3((n * d + 255) / 256), dim3(256), 0, s, pg_partial, meta + 2 * B, n, d, dT2);
     return check_launch("proto_grad_stage2");
 }
 

@@ -137,11 +137,12 @@ int colsum_dev(const float* X, int64_t rows, const int* rows_dev, int cols, int 
 // zero / zero_count: int32 words cleared by the same launches (the tail-split arrival counters)
 int graph_meta(const int32_t* extent, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, int32_t* zero,
                int zero_count, hipStream_t s);
+// all of dT2c: real rows from the arg-max routing, prototype rows (after the R real ones) as the ordered sum over
+// the graphs whose maximum they won; pg_partial: proto_grad_workspace() bytes
 int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta,
-                            int64_t B, int n, int d, float* dT2, int32_t* zero, int zero_count, hipStream_t s);
+                            int64_t B, int n, int d, float* dT2, float* pg_partial, int32_t* zero, int zero_count,
+                            hipStream_t s);
 size_t proto_grad_workspace(int n, int d);
-int proto_grad(const float* dpool, const int32_t* argmax, const int32_t* meta, int64_t B, int n, int d, float* partial,
-               float* dT2c, hipStream_t s);
 int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z,
                float* kl_partial, float* kl_out, hipStream_t s);
 // dmu / dlogvar rows have stride ld_out (d, or 2d when they are the two halves of one (B, 2d) matrix)
