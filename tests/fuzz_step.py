@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: the fused training step (losses, every gradient) against the CPU oracle over
-random (B, N, d, hid), eager and HIP-graph replay.  Usage: fuzz_step.py [cases] [seed]"""
+random (B, N, d, hid), eager and HIP-graph replay.  Usage: fuzz_step.py [cases] [seed] [big]
+("big": batches and widths large enough for the sparse second-layer weight gradient and the paired GEMMs)"""
 import os
 import sys
 
@@ -14,6 +15,7 @@ from oracle import graphvae_oracle as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 
 
 def relerr(a, b):
@@ -24,8 +26,12 @@ def relerr(a, b):
 worst = 0.0
 for c in range(cases):
     N = int(rng.choice([1, 2, 3, 5, 8, 10, 17, 31, 32, 33, 48, 63, 64]))
-    B = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 130, 257]))
-    d = int(rng.choice([1, 2, 3, 4, 8, 12, 30, 32, 64, 100, 128]))
+    if big:
+        B = int(rng.choice([257, 400, 512, 700, 1000]))
+        d = int(rng.choice([96, 128, 160, 256, 288, 512]))
+    else:
+        B = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 130, 257]))
+        d = int(rng.choice([1, 2, 3, 4, 8, 12, 30, 32, 64, 100, 128]))
     hid = int(rng.choice([1, 5, 16, 64, 96, 130]))
     params = O.init_params(N, d, hid, N, seed=c)
     for k in params:                      # random biases too (the reference's initialisers leave some at zero)
