@@ -246,9 +246,13 @@ constexpr int DW_THREADS = 512;
 constexpr int DW_COLS = 64;
 constexpr int DW_LD = 65;
 constexpr int DW_CPB = 512;   // pooled columns per block: 64 per wave
-constexpr int DW_GROUPS = 16;
+// 32 groups x 16 slabs at 2d = 1024: 512 blocks, two per CU (hence the bound of 4 waves per SIMD, 128 registers):
+// a block spends much of an item waiting (barriers, the dependent LDS reads of the adjacency walk) and the second
+// block fills those waits -- worth more than the second copy of the partials costs (16 groups, one block per
+// CU: 93 + 8 us; 32 groups: 13 us less per step).
+constexpr int DW_GROUPS = 32;
 
-__global__ __launch_bounds__(DW_THREADS) void dw2_sparse_kernel(const float* __restrict__ adj, const float* __restrict__ h1c,
+__global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* __restrict__ adj, const float* __restrict__ h1c,
                                                                 int ldh, const float* __restrict__ dpool,
                                                                 const int32_t* __restrict__ argmax,
                                                                 const int32_t* __restrict__ meta,
