@@ -100,34 +100,6 @@ struct Carver {
 
 inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
-// A second stream per device for a kernel that is independent of the work that follows it on the caller's stream
-// and bound by something else (issue and latency against the matrix pipe): fork after `s`, join back into `s`.
-// Works under stream capture (the side stream joins the capture at the fork and leaves it at the join).
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static std::mutex g_side_mu;
-static std::map<int, SideStream> g_side;
-
-int side_stream(SideStream* out)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return set_error(GTG_ERR_LAUNCH, "hipGetDevice failed");
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    auto it = g_side.find(dev);
-    if (it == g_side.end()) {
-        SideStream ss;
-        if (hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess)
-            return set_error(GTG_ERR_LAUNCH, "side stream: creation failed");
-        it = g_side.emplace(dev, ss).first;
-    }
-    *out = it->second;
-    return GTG_OK;
-}
-
 }  // namespace
 }  // namespace gtg
 
@@ -512,7 +484,7 @@ static void enc_cbwd_layout(Carver& c, int64_t B, int n, int d, EncCBwdWs* w)
                                                        (size_t)gemm_colsum_rows((int)rows) * H * sizeof(float))));
     w->slabs = reinterpret_cast<float*>(
         c.take<char>(max2(gemm_splitk_workspace(d, H, (int)rows, 1), gemm_splitk_workspace(H, n, (int)rows, 1))));
-    // its own partials: the sparse dW2 kernel runs beside the GEMMs that use `slabs`
+    // the sparse dW2 kernel's partials
     w->dw2 = reinterpret_cast<float*>(c.take<char>(dw2_sparse_applies(B, n, d, H) ? dw2_sparse_workspace(d, H) : 0));
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);
@@ -552,27 +524,8 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     // dW2 = dT2c^T * H1c: from the pooled gradient and the winning rows where the shape allows (one aggregated
     // row of H1c per graph and pooled column), else as the dense product
     static const bool dw2_dense = getenv("GTG_DW2_DENSE") && atoi(getenv("GTG_DW2_DENSE")) != 0;  // experiment hook
-    // It is bound by instruction issue and latency and the dZ1c GEMM by the matrix pipe, and neither needs the
-    // other's result: with GTG_DW2_SIDE=1 in the environment the sparse kernel goes to a side stream and is
-    // joined at the end of this call.  Measured: the step gains 1.6 % while the GEMM, sharing every CU's LDS and
-    // registers with a resident block of the sparse kernel, takes 0.218 ms instead of 0.158 ms.  Off by default:
-    // one stream, every kernel alone on the device and its duration its own.
-    static const bool dw2_inline = !(getenv("GTG_DW2_SIDE") && atoi(getenv("GTG_DW2_SIDE")) != 0);
-    SideStream side;
-    bool forked = false;
     if (!dw2_dense && dw2_sparse_applies(B, n, d, H)) {
-        hipStream_t ds = s;
-        if (!dw2_inline) {
-            GTG_TRY(side_stream(&side));
-            if (hipEventRecord(side.fork, s) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess)
-                return set_error(GTG_ERR_LAUNCH, "gtg_encoder_compact_bwd: fork failed");
-            forked = true;
-            ds = side.stream;
-        }
-        int rc = dw2_sparse(adj, h1c, H, dpooled, argmax, meta, w.dT2c, B, n, d, w.dw2, dW2, ds);
-        if (forked && hipEventRecord(side.join, side.stream) != hipSuccess)
-            return set_error(GTG_ERR_LAUNCH, "gtg_encoder_compact_bwd: join failed");
-        GTG_TRY(rc);
+        GTG_TRY(dw2_sparse(adj, h1c, H, dpooled, argmax, meta, w.dT2c, B, n, d, w.dw2, dW2, s));
     } else {
         g.A = w.dT2c; g.lda = d; g.a_kc = false;
         g.B = h1c; g.ldb = H; g.b_kc = false;
@@ -603,10 +556,7 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     g.B = adjc; g.ldb = n; g.b_kc = false;
     g.C = dW1; g.ldc = n; g.M = H; g.N = n; g.K = rows; g.k_dev = all_rows;
     g.splits = gemm_pick_splits(H, n, rows, 1); g.slabs = w.slabs;
-    const int rc_last = gemm(g, s);
-    if (forked && hipStreamWaitEvent(s, side.join, 0) != hipSuccess)
-        return set_error(GTG_ERR_LAUNCH, "gtg_encoder_compact_bwd: join failed");
-    return rc_last;
+    return gemm(g, s);
 }
 
 // ---------------------------------------------------------------------------
