@@ -693,14 +693,14 @@ size_t gtg_bce_workspace_bytes(int64_t num_graphs)
 }
 
 int gtg_bce_loss_fwd(const float* out, const float* adj_target, int64_t num_graphs, int n, float* loss, float* dlogits,
-                     void* ws, size_t ws_bytes, void* stream)
+                     const float* gscale_dev, void* ws, size_t ws_bytes, void* stream)
 {
     GTG_REQUIRE(num_graphs >= 1 && n >= 1, "bad size");
     GTG_REQUIRE(out && adj_target && loss, "null pointer");
     Carver c(ws, ws_bytes);
     float* partial = c.take<float>((size_t)num_graphs + 1);
     if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_bce_loss_fwd: workspace too small");
-    return bce_fwd(out, adj_target, num_graphs, n, partial, loss, dlogits, (hipStream_t)stream);
+    return bce_fwd(out, adj_target, num_graphs, n, partial, loss, dlogits, gscale_dev, (hipStream_t)stream);
 }
 
 int gtg_bce_loss_bwd(const float* out, const float* adj_target, float gscale, const float* gscale_dev,

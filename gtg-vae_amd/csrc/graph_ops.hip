@@ -401,9 +401,11 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
 // pass: gl / (B m) with gl as in bce_bwd_kernel below.)
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ out, const float* __restrict__ adj,
                                                       int n, int m, float* __restrict__ row_partial, float gscale,
+                                                      const float* __restrict__ gscale_dev,
                                                       float* __restrict__ dlogits)
 {
     __shared__ float sm[4];
+    if (gscale_dev != nullptr) gscale *= gscale_dev[0];
     const int64_t b = blockIdx.x;
     const float* o = out + b * m;
     const float* a = adj + b * n * n;
@@ -881,12 +883,12 @@ int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const
 }
 
 int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, float* dlogits,
-            hipStream_t s)
+            const float* gscale_dev, hipStream_t s)
 {
     const int m = n * (n + 1) / 2;
     if (B > 0) {
         hipLaunchKernelGGL(bce_fwd_kernel, dim3((unsigned)B), dim3(256), 0, s, out, adj, n, m, row_partial,
-                           m > 0 ? 1.f / ((float)B * (float)m) : 0.f, dlogits);
+                           m > 0 ? 1.f / ((float)B * (float)m) : 0.f, gscale_dev, dlogits);
         int rc = check_launch("bce_fwd_kernel");
         if (rc) return rc;
     }

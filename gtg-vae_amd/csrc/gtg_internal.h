@@ -150,7 +150,7 @@ int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const
                     float kl_scale, int64_t B, int d, int ld_out, float* dmu, float* dlogvar, hipStream_t s);
 // dlogits (nullable): gradient of the mean loss w.r.t. the pre-sigmoid logits, written in the same pass
 int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, float* dlogits,
-            hipStream_t s);
+            const float* gscale_dev, hipStream_t s);
 // gdev (nullable) is a device scalar multiplied into gscale (an upstream gradient).
 // through_sigmoid = 1: gradient w.r.t. the pre-sigmoid logits (BCE backward, then
 // the sigmoid's backward); 0: gradient w.r.t. the probabilities only.

@@ -102,6 +102,7 @@ class GraphBatch:
     num_nodes: torch.Tensor = None      # (B,) int32
     x: Optional[torch.Tensor] = None
     gold_bits: Optional[torch.Tensor] = field(default=None)  # (B, nmax) int64 bit masks
+    global_graphs: Optional[int] = None  # size of the global batch this one is a rank's shard of (None: not a shard)
 
     def dense_x(self) -> torch.Tensor:
         return torch.eye(self.nmax, dtype=torch.float, device=self.edge_index.device).repeat(self.num_graphs, 1)
@@ -109,13 +110,15 @@ class GraphBatch:
     def to(self, device) -> "GraphBatch":
         mv = lambda t: None if t is None else t.to(device, non_blocking=True)
         return GraphBatch(mv(self.edge_index), mv(self.batch), mv(self.adj_padded), self.gold_edges, self.snts,
-                          self.num_graphs, self.nmax, mv(self.num_nodes), mv(self.x), mv(self.gold_bits))
+                          self.num_graphs, self.nmax, mv(self.num_nodes), mv(self.x), mv(self.gold_bits),
+                          self.global_graphs)
 
     def pin_memory(self) -> "GraphBatch":
         """Host tensors in page-locked memory, so that ``to(device)`` is an asynchronous DMA."""
         pin = lambda t: None if t is None else (t if t.is_cuda or t.is_pinned() else t.pin_memory())
         return GraphBatch(pin(self.edge_index), pin(self.batch), pin(self.adj_padded), self.gold_edges, self.snts,
-                          self.num_graphs, self.nmax, pin(self.num_nodes), pin(self.x), pin(self.gold_bits))
+                          self.num_graphs, self.nmax, pin(self.num_nodes), pin(self.x), pin(self.gold_bits),
+                          self.global_graphs)
 
     def tensors(self):
         return [t for t in (self.edge_index, self.batch, self.adj_padded, self.num_nodes, self.x, self.gold_bits)
@@ -202,7 +205,8 @@ class DeviceDataset:
 
 class DeviceLoader:
     """Iterates a DeviceDataset as batches of graph ids (device int64 tensors); ``rank``/``world`` take this
-    rank's contiguous share of every batch.  ``GraphVAETrainer.load_indices`` consumes the ids."""
+    rank's contiguous share of every batch (sizes differ by at most one; on a ragged last batch a share can be
+    empty) and tag it with the global batch size.  ``GraphVAETrainer.load_indices`` consumes the ids."""
 
     def __init__(self, dataset: "DeviceDataset", batch_size: int, shuffle: bool = False, seed: int = 0, rank: int = 0,
                  world: int = 1):
@@ -217,9 +221,11 @@ class DeviceLoader:
     def __iter__(self):
         for ids in self.dataset.batches(self.batch_size, self.shuffle, self._gen):
             if self.world > 1:
-                base, rem = divmod(len(ids), self.world)
+                total = len(ids)
+                base, rem = divmod(total, self.world)
                 lo = self.rank * base + min(self.rank, rem)
-                ids = ids[lo:lo + base + (1 if self.rank < rem else 0)]
+                ids = ids[lo:lo + base + (1 if self.rank < rem else 0)]   # may be empty on the ragged last batch
+                ids.global_graphs = total    # the trainer weights this shard's gradient by len(ids) * world / total
             yield ids
 
 

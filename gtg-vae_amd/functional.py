@@ -254,7 +254,7 @@ class BCELossFn(torch.autograd.Function):
             raise _lib.GtgError(f"out {tuple(out.shape)} / adj {tuple(adj.shape)} do not match (B, n(n+1)/2) / (B, n, n)")
         loss = torch.empty((), dtype=torch.float32, device=out.device)
         ws = _ws(L.gtg_bce_workspace_bytes(B), out.device)
-        check(L.gtg_bce_loss_fwd(ptr(out), ptr(adj), B, n, ptr(loss), None, ptr(ws), ws.numel(), stream_ptr()),
+        check(L.gtg_bce_loss_fwd(ptr(out), ptr(adj), B, n, ptr(loss), None, None, ptr(ws), ws.numel(), stream_ptr()),
               "gtg_bce_loss_fwd")
         ctx.save_for_backward(out, adj)
         return loss

@@ -51,6 +51,12 @@ def shard_range(num_graphs: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_weight(local_graphs: int, global_graphs: int, world: int) -> float:
+    """Factor for a rank's mean-over-its-shard gradient so that sum all-reduce followed by 1/world gives the
+    mean over the global batch: B_local * world / B_global (1 when the shards are equal, 0 for an empty one)."""
+    return float(local_graphs) * world / float(global_graphs) if global_graphs else 1.0
+
+
 class GradBuckets:
     """Views of one flat gradient buffer, reduced bucket by bucket.
 

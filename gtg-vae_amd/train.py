@@ -77,6 +77,8 @@ def train(train_loader, dev_loader, trainer: GraphVAETrainer, epochs, model_name
             n_inst += B
         torch.cuda.synchronize(trainer.dev)
         dt = time.perf_counter() - t0
+        if not trainer.edges_ok():
+            raise RuntimeError("epoch %d: an edge left its graph or a gathered batch overflowed the edge buffer" % epoch)
         tot = torch.cat([sums, torch.tensor([float(n_inst)], dtype=torch.float64, device=trainer.dev)])
         if world > 1:
             from .parallel import all_reduce_small
@@ -118,7 +120,8 @@ class ShardedLoader:
 
 
 def slice_batch(batch, lo, hi):
-    """Graphs [lo, hi) of a collated batch (host tensors), renumbered from 0."""
+    """Graphs [lo, hi) of a collated batch (host tensors), renumbered from 0 and tagged with the size of the
+    batch they were cut from (the trainer weights an unequal shard's gradient by it); hi == lo is legal."""
     from .data import GraphBatch
 
     n = batch.nmax
@@ -128,7 +131,8 @@ def slice_batch(batch, lo, hi):
     ei = (ei[:, keep] - lo * n).contiguous()
     B = hi - lo
     return GraphBatch(ei, batch.batch[: B * n].clone(), batch.adj_padded[lo:hi].contiguous(), batch.gold_edges[lo:hi],
-                      batch.snts[lo:hi], B, n, batch.num_nodes[lo:hi], None, batch.gold_bits[lo:hi].contiguous())
+                      batch.snts[lo:hi], B, n, batch.num_nodes[lo:hi], None, batch.gold_bits[lo:hi].contiguous(),
+                      batch.num_graphs)
 
 
 def main(argv=None):

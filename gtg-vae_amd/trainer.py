@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr
 from .data import GraphBatch
-from .parallel import GradBuckets
+from .parallel import GradBuckets, shard_weight
 
 # (state_dict key, shape as a function of (f, d, hid, m)); bucket 0 = decoder +
 # latent head (gradients final before the encoder's backward starts), bucket 1 = encoder.
@@ -87,7 +87,13 @@ class GraphVAETrainer:
         self.world = self.buckets.world
         self._init_params(init, seed)
 
-        self.kl_w_dev = torch.ones(1, dtype=torch.float32, device=self.dev)
+        # device scalars the captured step reads: [0] kl_w * shard weight (the KL term's factor in the backward),
+        # [1] shard weight alone (the reconstruction gradient's factor).  The shard weight B_local * world /
+        # B_global makes the sum all-reduce + 1/world of Adam the full-batch mean even when the ranks'
+        # shards of a batch are unequal; it is 1 otherwise.
+        self.kl_w_dev = torch.ones(2, dtype=torch.float32, device=self.dev)
+        self._kl_w, self._shard_w = 1.0, 1.0
+        self._B = 0
         self._cap_B = 0
         self._cap_E = 0
         self._graph = None
@@ -104,11 +110,23 @@ class GraphVAETrainer:
             torch.manual_seed(seed)
             model = GTVAE(self.f, self.d, self.hid, self.n, text=False)
             init = {k.replace("graph_vae.", ""): v for k, v in model.state_dict().items()}
+        loaded = set()
         with torch.no_grad():
             for k, v in init.items():
                 k = k.replace("graph_vae.", "")
+                # torch_geometric 1.x checkpoints keep GCNConv's weight as `<conv>.weight` with shape (in, out)
+                for conv in ("encoder.conv1", "encoder.conv2"):
+                    if k == conv + ".weight":
+                        k, v = conv + ".lin.weight", v.t()
                 if k in self.p:
+                    if tuple(v.shape) != tuple(self.p[k].shape):
+                        raise _lib.GtgError("parameter %s has shape %s, expected %s" % (k, tuple(v.shape),
+                                                                                          tuple(self.p[k].shape)))
                     self.p[k].copy_(v.to(self.dev, torch.float32))
+                    loaded.add(k)
+        missing = [k for k in self.p if k not in loaded]
+        if missing:
+            raise _lib.GtgError("state dict does not cover the parameters %s" % missing)
 
     def named_params(self) -> Dict[str, torch.Tensor]:
         return self.p
@@ -164,11 +182,17 @@ class GraphVAETrainer:
         self._cap_B, self._cap_E = B, E
         self._graph = None
 
-    def load_batch(self, batch: GraphBatch, eps: torch.Tensor):
+    def load_batch(self, batch: GraphBatch, eps: torch.Tensor, global_graphs: Optional[int] = None):
         """Copy one batch into the step's static input buffers.  The edge list
         is padded to capacity with (0,0) self loops, which the adjacency kernel
-        drops, so the launch shapes do not depend on the number of edges."""
+        drops, so the launch shapes do not depend on the number of edges.
+        ``global_graphs`` (default: the batch's own ``global_graphs`` field): size of the global batch
+        this rank's shard was cut from, when the shards of the ranks may be unequal.  A shard of zero graphs
+        is legal: the rank then contributes zero gradients and still joins the all-reduces."""
         B, E = batch.num_graphs, batch.edge_index.shape[1]
+        if B == 0:
+            self._B = 0
+            return
         self._ensure_capacity(B, E)
         ei, adj = batch.edge_index, batch.adj_padded
         if (ei.is_cuda and adj.is_cuda and eps.is_cuda and ei.dtype == torch.int64 and ei.is_contiguous()
@@ -184,11 +208,28 @@ class GraphVAETrainer:
             self.target[:B].copy_(adj, non_blocking=True)
             self.eps_buf[:B].copy_(eps, non_blocking=True)
         self._B = B
+        self._set_shard_weight(B, getattr(batch, "global_graphs", None) if global_graphs is None else global_graphs)
 
-    def load_indices(self, dataset, graph_ids: torch.Tensor, eps: torch.Tensor):
+    def _set_shard_weight(self, B: int, global_graphs):
+        w = shard_weight(B, global_graphs, self.world)
+        if w != self._shard_w:
+            self._shard_w = w
+            self._push_weights()
+
+    def _push_weights(self):
+        self.kl_w_dev[0:1].fill_(self._kl_w * self._shard_w)   # stream-ordered fills: no host sync
+        self.kl_w_dev[1:2].fill_(self._shard_w)
+
+    def load_indices(self, dataset, graph_ids: torch.Tensor, eps: torch.Tensor, global_graphs: Optional[int] = None):
         """Assemble the batch of ``graph_ids`` (int64, on the device) from a ``data.DeviceDataset`` straight into
-        the step's static buffers: two kernel launches, nothing read back."""
+        the step's static buffers: two kernel launches, nothing read back.  ``global_graphs``: as load_batch
+        (default: the ``global_graphs`` attribute DeviceLoader sets on the ids it yields)."""
         B = int(graph_ids.numel())
+        if B == 0:
+            self._B = 0
+            return
+        if global_graphs is None:
+            global_graphs = getattr(graph_ids, "global_graphs", None)
         self._ensure_capacity(B, B * max(dataset.max_edges_per_graph, 1))
         if dataset.nmax != self.n:
             raise _lib.GtgError("dataset nmax %d != trainer nmax %d" % (dataset.nmax, self.n))
@@ -200,6 +241,7 @@ class GraphVAETrainer:
               "gtg_gather_batch")
         self.eps_buf[:B].copy_(eps, non_blocking=True)
         self._B = B
+        self._set_shard_weight(B, global_graphs)
 
     # ------------------------------------------------------------------ the step
     # The step is three runs of launches with the two gradient all-reduces between
@@ -227,7 +269,8 @@ class GraphVAETrainer:
                                 ptr(self.y1), ptr(self.out), stream), "gtg_decoder_fwd")
         # with a backward to follow, the loss kernel leaves its gradient w.r.t. the logits on the way
         check(L.gtg_bce_loss_fwd(ptr(self.out), ptr(self.target), B, n, self.scalars.data_ptr(),
-                                 ptr(self.dlogits) if backward else None, ws, wsn, stream), "gtg_bce_loss_fwd")
+                                 ptr(self.dlogits) if backward else None, self.kl_w_dev[1:].data_ptr(), ws, wsn,
+                                 stream), "gtg_bce_loss_fwd")
 
     def _seg_head_backward(self, B: int, stream: int):
         """Decoder and latent head: their gradients (bucket 0) are final after this."""
@@ -293,13 +336,23 @@ class GraphVAETrainer:
         self._run_segments([None if f is None else (lambda f=f: f(stream)) for f in segs], update)
 
     def set_kl_weight(self, kl_w: float):
-        self.kl_w_dev.fill_(float(kl_w))
+        if float(kl_w) != self._kl_w:
+            self._kl_w = float(kl_w)
+            self._push_weights()
 
     def run_loaded(self, update: bool = True, use_graph: bool = False):
         """One step on the batch already in the static buffers.  With
         ``use_graph`` the launches between the all-reduces are replayed as HIP
         graphs (captured on first use for this batch size)."""
         B = self._B
+        if B == 0:
+            # this rank's shard of the batch is empty: zero gradients, same collectives, same optimiser step
+            self.flat_g.zero_()
+            self.scalars.zero_()
+            if update:
+                self.buckets.reduce_all()
+                self._seg_adam(torch.cuda.current_stream(self.dev).cuda_stream)
+            return {"recon": self.scalars[0], "kl": self.scalars[1]}
         if use_graph:
             key = (B, update, self.ei.shape[1])
             if self._graph is None or self._graph_key != key:
@@ -328,7 +381,9 @@ class GraphVAETrainer:
                 graphs.append(None)
                 continue
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: a loader thread that pins or copies on this device meanwhile (data.DevicePrefetcher)
+            # must not invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 f(torch.cuda.current_stream(self.dev).cuda_stream)
             graphs.append(g)
         self.flat_p.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])

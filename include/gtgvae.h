@@ -171,7 +171,9 @@ int gtg_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, c
  * (B, n(n+1)/2), may be NULL: the gradient of that loss w.r.t. the decoder's
  * pre-sigmoid logits, written in the same pass (a training step then needs no
  * separate backward launch for the loss: hand it to gtg_decoder_bwd as dout
- * with out = NULL).
+ * with out = NULL); it is multiplied by *gscale_dev when that device scalar is
+ * given (NULL = 1): the weight B_local * world / B_global of this rank's shard
+ * in a data-parallel step whose shards are unequal.  `loss` is never scaled.
  * gtg_bce_loss_bwd: gradient of that loss times gscale * (*gscale_dev if
  * non-NULL), w.r.t. `out` (through_sigmoid = 0) or the logits (= 1).
  * gtg_decoder_bwd: give either dout (gradient w.r.t. out; w.r.t. the logits
@@ -180,7 +182,7 @@ int gtg_decoder_fwd(const float* z, const float* D1, const float* c1, const floa
                     int64_t num_graphs, int d, int hid, int m_out, float* y1, float* out, void* stream);
 size_t gtg_bce_workspace_bytes(int64_t num_graphs);
 int gtg_bce_loss_fwd(const float* out, const float* adj_target, int64_t num_graphs, int n, float* loss, float* dlogits,
-                     void* ws, size_t ws_bytes, void* stream);
+                     const float* gscale_dev, void* ws, size_t ws_bytes, void* stream);
 int gtg_bce_loss_bwd(const float* out, const float* adj_target, float gscale, const float* gscale_dev,
                      int64_t num_graphs, int n, int through_sigmoid, float* grad, void* stream);
 size_t gtg_decoder_bwd_workspace_bytes(int64_t num_graphs, int d, int hid, int m_out);

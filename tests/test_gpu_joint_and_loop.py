@@ -222,12 +222,15 @@ def test_device_prefetcher_yields_the_loaders_batches_in_order():
         assert torch.equal(g.adj_padded.cpu(), w.adj_padded) and torch.equal(g.gold_bits.cpu(), w.gold_bits)
         assert g.gold_edges == w.gold_edges and g.num_graphs == w.num_graphs
     runs = []
-    for wrap in (False, True):
+    # the third arm captures the step's HIP graphs while the prefetcher's worker thread pins and copies batches
+    for wrap, use_graph in ((False, False), (True, False), (True, True)):
         tr = GraphVAETrainer(N, 16, 32, N, device="cuda", seed=1)
         ld = DevicePrefetcher(loader, "cuda") if wrap else loader
-        hist = train(ld, None, tr, epochs=2, generator=torch.Generator().manual_seed(0), quiet=True)
+        hist = train(ld, None, tr, epochs=2, generator=torch.Generator().manual_seed(0), quiet=True,
+                     use_graph=use_graph)
         runs.append((tr.flat_p.clone(), hist[-1]["loss"]))
     assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    assert torch.equal(runs[0][0], runs[2][0]) and runs[0][1] == runs[2][1]
 
     # an exception in the worker surfaces in the consumer
     class Boom:
