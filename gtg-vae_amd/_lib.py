@@ -45,6 +45,8 @@ _SIGS = {
     "gtg_decoder_fwd": (c_int, [_P] * 5 + [c_int64, c_int, c_int, c_int] + [_P, _P, _P]),
     "gtg_bce_workspace_bytes": (c_size_t, [c_int64]),
     "gtg_bce_loss_fwd": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "gtg_bce_loss_fwd_noalloc_max_graphs": (c_int64, []),
+    "gtg_bce_loss_fwd_noalloc": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, _P]),
     "gtg_bce_loss_bwd": (c_int, [_P, _P, c_float, _P, c_int64, c_int, c_int, _P, _P]),
     "gtg_decoder_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "gtg_decoder_bwd": (c_int, [_P] * 7 + [c_int, c_float, _P, c_int64, c_int, c_int, c_int] + [_P] * 5 + [_P, c_size_t, _P]),

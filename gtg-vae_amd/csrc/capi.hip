@@ -703,6 +703,18 @@ int gtg_bce_loss_fwd(const float* out, const float* adj_target, int64_t num_grap
     return bce_fwd(out, adj_target, num_graphs, n, partial, loss, dlogits, gscale_dev, (hipStream_t)stream);
 }
 
+// gtg_bce_loss_fwd for callers that cannot allocate: no workspace argument, the per-graph partial sums go to
+// a device array that is part of the library's code object.
+int64_t gtg_bce_loss_fwd_noalloc_max_graphs(void) { return bce_static_max_graphs(); }
+
+int gtg_bce_loss_fwd_noalloc(const float* out, const float* adj_target, int64_t num_graphs, int n, float* loss,
+                             float* dlogits, const float* gscale_dev, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && n >= 1 && n <= 64, "bad size");
+    GTG_REQUIRE(out && adj_target && loss, "null pointer");
+    return bce_fwd_static(out, adj_target, num_graphs, n, loss, dlogits, gscale_dev, (hipStream_t)stream);
+}
+
 int gtg_bce_loss_bwd(const float* out, const float* adj_target, float gscale, const float* gscale_dev,
                      int64_t num_graphs, int n, int through_sigmoid, float* grad, void* stream)
 {

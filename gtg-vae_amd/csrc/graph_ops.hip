@@ -6,6 +6,8 @@
 // Every reduction here is ordered (per-block tree in LDS, then a fixed-order
 // pass over the partials): the same inputs give bit-identical outputs, and no
 // float atomics are used.
+#include <mutex>
+
 #include "gtg_internal.h"
 
 namespace gtg {
@@ -895,6 +897,50 @@ int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_par
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, row_partial, B,
                        (B > 0 && m > 0) ? 1.f / ((float)B * (float)m) : 0.f, loss);
     return check_launch("final_sum_kernel");
+}
+
+// ---------------------------------------------------------------------------
+// Allocation-free form of the reconstruction loss.  The per-graph partial sums
+// (device memory beyond the call's inputs and outputs) live in a file-scope
+// device array instead of a caller workspace.  Every GPU the library runs on
+// holds its own copy of the array, at its own address: that address is looked
+// up once per device, with that device current, and kept; `bce_scratch` itself
+// is only the host-side handle the lookup takes and never a kernel argument.
+// Nothing in the array has to start at zero (bce_fwd_kernel writes entry b of
+// every graph b < B before final_sum_kernel reads entries [0, B)), so a call
+// leaves no state behind that a later, smaller call could pick up.
+// ---------------------------------------------------------------------------
+constexpr int64_t BCE_STATIC_MAX_GRAPHS = 65536;
+constexpr int BCE_STATIC_MAX_DEVICES = 64;
+static __device__ __align__(256) float bce_scratch[BCE_STATIC_MAX_GRAPHS + 64];
+static std::mutex g_bce_scratch_mu;
+static float* g_bce_scratch_ptr[BCE_STATIC_MAX_DEVICES] = {};
+
+int64_t bce_static_max_graphs() { return BCE_STATIC_MAX_GRAPHS; }
+
+int bce_fwd_static(const float* out, const float* adj, int64_t B, int n, float* loss, float* dlogits,
+                   const float* gscale_dev, hipStream_t s)
+{
+    if (B > BCE_STATIC_MAX_GRAPHS)
+        return set_error(GTG_ERR_UNSUPPORTED, "gtg_bce_loss_fwd_noalloc: %lld graphs exceed the static scratch (%lld)",
+                         (long long)B, (long long)BCE_STATIC_MAX_GRAPHS);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BCE_STATIC_MAX_DEVICES)
+        return set_error(GTG_ERR_UNSUPPORTED, "gtg_bce_loss_fwd_noalloc: no current device, or device index >= %d",
+                         BCE_STATIC_MAX_DEVICES);
+    float* ptr;
+    {
+        std::lock_guard<std::mutex> lk(g_bce_scratch_mu);
+        ptr = g_bce_scratch_ptr[dev];
+        if (ptr == nullptr) {
+            // first call on this device: the array's address in THIS device's copy of the code object
+            const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(bce_scratch));
+            if (e != hipSuccess || ptr == nullptr)
+                return set_error(GTG_ERR_LAUNCH, "gtg_bce_loss_fwd_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            g_bce_scratch_ptr[dev] = ptr;
+        }
+    }
+    return bce_fwd(out, adj, B, n, ptr, loss, dlogits, gscale_dev, s);
 }
 
 int bce_bwd(const float* out, const float* adj, int64_t B, int n, const float* gdev, float gscale,

@@ -151,6 +151,10 @@ int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const
 // dlogits (nullable): gradient of the mean loss w.r.t. the pre-sigmoid logits, written in the same pass
 int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, float* dlogits,
             const float* gscale_dev, hipStream_t s);
+// the same with the per-graph partial sums in a file-scope device array (no workspace argument, nothing allocated)
+int bce_fwd_static(const float* out, const float* adj, int64_t B, int n, float* loss, float* dlogits,
+                   const float* gscale_dev, hipStream_t s);
+int64_t bce_static_max_graphs();
 // gdev (nullable) is a device scalar multiplied into gscale (an upstream gradient).
 // through_sigmoid = 1: gradient w.r.t. the pre-sigmoid logits (BCE backward, then
 // the sigmoid's backward); 0: gradient w.r.t. the probabilities only.

@@ -185,6 +185,23 @@ int gtg_bce_loss_fwd(const float* out, const float* adj_target, int64_t num_grap
                      const float* gscale_dev, void* ws, size_t ws_bytes, void* stream);
 int gtg_bce_loss_bwd(const float* out, const float* adj_target, float gscale, const float* gscale_dev,
                      int64_t num_graphs, int n, int through_sigmoid, float* grad, void* stream);
+
+/* gtg_bce_loss_fwd without a workspace and without any allocation: same
+ * arguments otherwise, same kernels, bit-identical loss and dlogits.  It has NO
+ * counterpart in the reference; it exists for callers that cannot allocate
+ * device memory around the call (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  The per-graph partial sums go to a
+ * device array inside the library's code object (256 KB per GPU, held until the
+ * process ends), so num_graphs is limited to
+ * gtg_bce_loss_fwd_noalloc_max_graphs() = 65536; a larger batch is rejected
+ * with GTG_ERR_UNSUPPORTED.  The first call on each device looks the array's
+ * address up (no allocation; make that call outside graph capture), with
+ * `stream` belonging to the current device.  All calls on one GPU share the
+ * array: two calls that overlap on one GPU (different streams) race; calls
+ * ordered on one stream, or on different GPUs, are safe. */
+int64_t gtg_bce_loss_fwd_noalloc_max_graphs(void);
+int gtg_bce_loss_fwd_noalloc(const float* out, const float* adj_target, int64_t num_graphs, int n, float* loss,
+                             float* dlogits, const float* gscale_dev, void* stream);
 size_t gtg_decoder_bwd_workspace_bytes(int64_t num_graphs, int d, int hid, int m_out);
 int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const float* y1, const float* out,
                     const float* dout, const float* adj_target, int n, float gscale, const float* gscale_dev,
