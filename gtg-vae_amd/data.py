@@ -23,6 +23,7 @@ class GraphData:
     snts: str = ""
     num_nodes: int = 0
     maxnode: int = 0
+    tokens: Optional[List[int]] = None  # token ids of ``snts`` (what train.py:305 gets from the tokenizer), if known
 
     @property
     def x(self) -> torch.Tensor:
@@ -69,7 +70,7 @@ def prep_graph(graph: dict, maxnode: int) -> Optional[GraphData]:
     adj_padded = np.zeros((maxnode, maxnode))
     adj_padded[:num_of_nodes, :num_of_nodes] = adj
     ei = torch.tensor(edges, dtype=torch.long).reshape(-1, 2).t().contiguous()
-    return GraphData(ei, set(gold), adj_padded, graph.get("input", ""), num_of_nodes, maxnode)
+    return GraphData(ei, set(gold), adj_padded, graph.get("input", ""), num_of_nodes, maxnode, graph.get("tokens"))
 
 
 def prep_data_list(graphs: Iterable[dict], maxnode: int) -> List[GraphData]:
@@ -103,6 +104,7 @@ class GraphBatch:
     x: Optional[torch.Tensor] = None
     gold_bits: Optional[torch.Tensor] = field(default=None)  # (B, nmax) int64 bit masks
     global_graphs: Optional[int] = None  # size of the global batch this one is a rank's shard of (None: not a shard)
+    dec_seq: Optional[torch.Tensor] = None  # (B, T) int64 token ids padded with 0 to the batch's longest sentence
 
     def dense_x(self) -> torch.Tensor:
         return torch.eye(self.nmax, dtype=torch.float, device=self.edge_index.device).repeat(self.num_graphs, 1)
@@ -111,18 +113,18 @@ class GraphBatch:
         mv = lambda t: None if t is None else t.to(device, non_blocking=True)
         return GraphBatch(mv(self.edge_index), mv(self.batch), mv(self.adj_padded), self.gold_edges, self.snts,
                           self.num_graphs, self.nmax, mv(self.num_nodes), mv(self.x), mv(self.gold_bits),
-                          self.global_graphs)
+                          self.global_graphs, mv(self.dec_seq))
 
     def pin_memory(self) -> "GraphBatch":
         """Host tensors in page-locked memory, so that ``to(device)`` is an asynchronous DMA."""
         pin = lambda t: None if t is None else (t if t.is_cuda or t.is_pinned() else t.pin_memory())
         return GraphBatch(pin(self.edge_index), pin(self.batch), pin(self.adj_padded), self.gold_edges, self.snts,
                           self.num_graphs, self.nmax, pin(self.num_nodes), pin(self.x), pin(self.gold_bits),
-                          self.global_graphs)
+                          self.global_graphs, pin(self.dec_seq))
 
     def tensors(self):
-        return [t for t in (self.edge_index, self.batch, self.adj_padded, self.num_nodes, self.x, self.gold_bits)
-                if t is not None]
+        return [t for t in (self.edge_index, self.batch, self.adj_padded, self.num_nodes, self.x, self.gold_bits,
+                            self.dec_seq) if t is not None]
 
     def __len__(self):
         return self.num_graphs
@@ -146,7 +148,21 @@ def collate(data_list: Sequence[GraphData], nmax: int) -> GraphBatch:
     gold = [d.gold_edges for d in data_list]
     nn = torch.tensor([d.num_nodes for d in data_list], dtype=torch.int32)
     bits = torch.stack([d.gold_row() for d in data_list]) if B else torch.zeros((0, nmax), dtype=torch.int64)
-    return GraphBatch(ei.contiguous(), batch, adj, gold, [d.snts for d in data_list], B, nmax, nn, None, bits)
+    return GraphBatch(ei.contiguous(), batch, adj, gold, [d.snts for d in data_list], B, nmax, nn, None, bits,
+                      dec_seq=pad_tokens([d.tokens for d in data_list]))
+
+
+def pad_tokens(token_lists, pad: int = 0) -> Optional[torch.Tensor]:
+    """(B, T) int64, every sentence padded with ``pad`` to the longest of the batch -- what
+    ``tokenizer(snts, padding=True)['input_ids']`` hands the model at train.py:305.  None when a
+    graph carries no token ids."""
+    if not token_lists or any(t is None for t in token_lists):
+        return None
+    T = max(len(t) for t in token_lists)
+    out = np.full((len(token_lists), T), pad, dtype=np.int64)
+    for b, t in enumerate(token_lists):
+        out[b, :len(t)] = t
+    return torch.from_numpy(out)
 
 
 class DataLoader:
@@ -312,9 +328,24 @@ def synth_mrp_graph(rng: np.random.Generator, nmax: int) -> dict:
     return {"nodes": [{"id": i} for i in range(n)], "edges": edges, "input": "synthetic sentence %d" % n}
 
 
-def synth_graph_list(num: int, nmax: int, seed: int = 1234) -> List[GraphData]:
+def synth_graph_list(num: int, nmax: int, seed: int = 1234, vocab: int = 0, max_len: int = 40) -> List[GraphData]:
+    """``vocab`` > 0 also attaches a synthetic sentence to every graph (``synth_tokens``)."""
     rng = np.random.default_rng(seed)
-    return prep_data_list([synth_mrp_graph(rng, nmax) for _ in range(num)], nmax)
+    out = prep_data_list([synth_mrp_graph(rng, nmax) for _ in range(num)], nmax)
+    if vocab:
+        for d in out:
+            d.tokens = synth_tokens(rng, vocab, max_len)
+    return out
+
+
+def synth_tokens(rng: np.random.Generator, vocab: int = 30522, max_len: int = 40) -> List[int]:
+    """A sentence shaped like bert-base-uncased output: length T ~ U{8..max_len} including the start (101)
+    and end (102) symbols, word-piece ids uniform in [1000, vocab); small vocabularies use [3, vocab)."""
+    T = int(rng.integers(min(8, max_len), max_len + 1))
+    lo = 1000 if vocab > 2000 else 3
+    body = rng.integers(lo, vocab, size=max(T - 2, 0)).tolist()
+    first, last = (101, 102) if vocab > 102 else (1, 2)
+    return [first] + body + [last]
 
 
 def synth_graph_batch(B: int, nmax: int, seed: int = 1234) -> GraphBatch:

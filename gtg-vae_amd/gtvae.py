@@ -34,6 +34,9 @@ class GTVAE(nn.Module):
         self.phase = phase
         self.train_graph_recon = (not text) if train_graph_recon is None else train_graph_recon
         self.eps_generator = None  # optional torch.Generator for reproducible latent noise
+        # True: text accuracy is returned as a Python float like the reference's (a host sync per call);
+        # False: as a 0-dim device tensor
+        self.host_metrics = True
 
     def _eps(self, like):
         return torch.randn(like.shape, dtype=like.dtype, device=like.device, generator=self.eps_generator)
@@ -49,14 +52,13 @@ class GTVAE(nn.Module):
         return kl
 
     # gtvae.py:77-91
-    def forward_1(self, inputs, targets):
+    def forward_1(self, inputs, targets, eps=None):
         text_h = self.text_vae.autoenc(inputs, targets)
-        text_mu = self.zg_mu(text_h)
-        text_var = self.zg_var(text_h)
-        text_z, text_kl_loss = Fn.ReparamKLFn.apply(text_mu, text_var, self._eps(text_mu))
+        text_z, text_kl_loss, _, _ = Fn.LatentFn.apply(text_h, self.zg_mu.weight, self.zg_mu.bias, self.zg_var.weight,
+                                                       self.zg_var.bias, self._eps(text_h) if eps is None else eps)
         tok_loss, pred, _ = self.text_vae.decode_loss(text_z, inputs, targets)
         text_recon_loss = tok_loss.sum(dim=0).mean()
-        text_acc = self.text_vae.accuracy_from_pred(pred, targets)
+        text_acc = self.text_vae.accuracy_from_pred(pred, targets, self.host_metrics)
         return text_kl_loss + text_recon_loss, text_acc
 
     # gtvae.py:95-126
@@ -81,7 +83,7 @@ class GTVAE(nn.Module):
         if self.text_vae is not None:
             tok_loss, pred, _ = self.text_vae.decode_loss(joint_z, inputs, targets)
             text_recon_loss = tok_loss.sum(dim=0).mean()
-            text_acc = self.text_vae.accuracy_from_pred(pred, targets)
+            text_acc = self.text_vae.accuracy_from_pred(pred, targets, self.host_metrics)
             loss = loss + text_recon_loss
         out_tensor = self.graph_vae.decode(joint_z)
         graph_recon_loss, edge_recall, edge_precision = self.graph_vae.loss(out_tensor, adj, gold_edges, report)

@@ -36,6 +36,7 @@ class DAE(TextModel):
         self.hgen = nn.Linear(2048, latent_dim)
         self.z2emb = nn.Linear(latent_dim, 512)
         self.padidx = padidx
+        self.word_drop = 0.3   # probability with which training drops a word of the encoder's input (text_vae.py:70)
 
     def flatten(self):
         self.E.flatten_parameters()
@@ -68,12 +69,13 @@ class DAE(TextModel):
                                 targets.reshape(-1), self.padidx, matrix_mode)
         return loss.view(targets.size()), pred.view(targets.size()), hidden
 
-    def accuracy_from_pred(self, pred, targets):
+    def accuracy_from_pred(self, pred, targets, as_float=True):
         mask = targets != self.padidx
-        return (((pred == targets) & mask).sum() / mask.sum()).item()
+        acc = ((pred == targets) & mask).sum() / mask.sum()
+        return acc.item() if as_float else acc
 
     def forward(self, input):
-        _input = noisy(self.padidx, input, 0.3, 0, 0, 0) if self.training else input
+        _input = noisy(self.padidx, input, self.word_drop, 0, 0, 0) if self.training and self.word_drop > 0 else input
         return self.encode(_input)
 
     def loss_rec(self, logits, targets):

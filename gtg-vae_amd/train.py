@@ -102,6 +102,90 @@ def train(train_loader, dev_loader, trainer: GraphVAETrainer, epochs, model_name
     return history
 
 
+def _print_epoch(tag, epoch, m, kl_anneal_w=None, graphs_per_s=None):
+    """The reference's epoch report (train.py:343-352, dev: 273-279), same field names and formats."""
+    print("DEV" if tag == "dev" else "\n ============================")
+    print("Epoch: {}".format(epoch))
+    print("Epoch loss: {:.3f}".format(m["loss"]))
+    print("Epoch graph_recon loss: {:.3f}".format(m["graph_recon"]), "Epoch text_recon_loss: {:.3f}".format(m["text_recon"]))
+    print("Epoch joint_kl_loss: {:.3f}".format(m["kl"]))
+    print("Epoch edge_recall: {:.3f}".format(m["edge_recall"]), "Epoch edge_precision: {:.3f}".format(m["edge_precision"]))
+    print("Epoch text_acc: {:.3f}".format(m["text_acc"]))
+    if kl_anneal_w is not None:
+        print("kl_anneal_w:", kl_anneal_w)
+    if graphs_per_s is not None:
+        print("graphs/s: {:.0f}".format(graphs_per_s))
+
+
+_JOINT_FIELDS = ("loss", "text_acc", "kl", "graph_recon", "text_recon", "edge_recall", "edge_precision")
+
+
+def dev_joint(loader, trainer, epoch, kl_anneal_w, generator=None, quiet=False):
+    """dev() of train.py:228-282 for the joint model: eval mode (no dropout, no word noise; the latent is
+    still sampled, gtvae.py:34), batch-size-weighted means, spanning-tree edge recall / precision reported."""
+    was_training = trainer.model.training
+    trainer.model.eval()
+    sums = torch.zeros(len(_JOINT_FIELDS), dtype=torch.float64)
+    n_inst = 0
+    for batch in loader:
+        B = batch.num_graphs
+        eps = torch.randn(B, trainer.d, generator=generator).to(trainer.dev)
+        gb = batch.to(trainer.dev)
+        res = trainer.evaluate(gb, gb.dec_seq, eps, kl_anneal_w, report=True)
+        sums += torch.stack([torch.as_tensor(res[k], dtype=torch.float64).cpu() for k in _JOINT_FIELDS]) * B
+        n_inst += B
+    trainer.model.train(was_training)
+    means = dict(zip(_JOINT_FIELDS, (sums / max(n_inst, 1)).tolist()))
+    if not quiet:
+        _print_epoch("dev", epoch, means)
+    return means
+
+
+def train_joint(train_loader, dev_loader, trainer, epochs, model_name="gtg", rank=0, world=1, generator=None,
+                quiet=False, save_every=0):
+    """train() of train.py:284-355 for the joint graph+text model: model.train() (dropout 0.5 and word drop
+    0.3 on), KL weight min(epoch/500, 1) per epoch, one JointTrainer.step per batch (every rank on its shard of
+    it), batch-size-weighted epoch means accumulated on the device, the reference's printed fields."""
+    if rank == 0 and not quiet:
+        print("trnsize: {}, devsize: {}, num_epochs: {}, nkl: {}, at: {}, lr: {}".format(
+            len(train_loader.dataset), len(dev_loader.dataset) if dev_loader else 0, epochs, NKL, 0.3, trainer.lr))
+    fields = _JOINT_FIELDS[:5]
+    history = []
+    for epoch in range(epochs):
+        trainer.model.train()
+        kl_anneal_w = min(epoch / NKL, 1)
+        sums = torch.zeros(len(fields), dtype=torch.float64, device=trainer.dev)
+        n_inst = 0
+        t0 = time.perf_counter()
+        for batch in train_loader:
+            if world > 1 and not getattr(train_loader, "sharded", False):
+                lo, hi = shard_range(batch.num_graphs, rank, world)
+                batch = slice_batch(batch, lo, hi)
+            B = batch.num_graphs
+            eps = torch.randn(B, trainer.d, generator=generator).to(trainer.dev)
+            gb = batch if batch.edge_index.is_cuda else batch.to(trainer.dev)
+            res = trainer.step(gb, gb.dec_seq, eps, kl_anneal_w, update=True)
+            sums += torch.stack([res[k].double() for k in fields]) * B
+            n_inst += B
+        torch.cuda.synchronize(trainer.dev)
+        dt = time.perf_counter() - t0
+        tot = torch.cat([sums, torch.tensor([float(n_inst)], dtype=torch.float64, device=trainer.dev)])
+        if world > 1:
+            from .parallel import all_reduce_small
+
+            tot = all_reduce_small(tot)
+        means = dict(zip(fields, (tot[:-1] / tot[-1]).tolist()))
+        means.update(edge_recall=0.0, edge_precision=0.0)   # training passes report=False (gtvae.py:123)
+        history.append(dict(means, epoch=epoch, graphs_per_s=tot[-1].item() / dt))
+        if rank == 0 and not quiet:
+            _print_epoch("train", epoch, means, kl_anneal_w, tot[-1].item() / dt)
+        if dev_loader is not None and rank == 0:
+            history[-1]["dev"] = dev_joint(dev_loader, trainer, epoch, kl_anneal_w, generator, quiet)
+        if save_every and rank == 0 and epoch % save_every == 0:
+            torch.save(trainer.state_dict(), "%s_%d" % (model_name, epoch))
+    return history
+
+
 class ShardedLoader:
     """This rank's contiguous share of every batch of ``loader`` (host side, before any copy)."""
     sharded = True
@@ -132,7 +216,10 @@ def slice_batch(batch, lo, hi):
     B = hi - lo
     return GraphBatch(ei, batch.batch[: B * n].clone(), batch.adj_padded[lo:hi].contiguous(), batch.gold_edges[lo:hi],
                       batch.snts[lo:hi], B, n, batch.num_nodes[lo:hi], None, batch.gold_bits[lo:hi].contiguous(),
-                      batch.num_graphs)
+                      batch.num_graphs,
+                      # all T columns are kept: the text encoder reads the padding too (text_vae.py:56 runs the LSTM
+                      # over the padded batch), so a shard must see the sentence length of the whole batch
+                      None if batch.dec_seq is None else batch.dec_seq[lo:hi].contiguous())
 
 
 def main(argv=None):
@@ -153,6 +240,12 @@ def main(argv=None):
                     help="collate every batch on the host (as the reference does) instead of keeping the training "
                          "set in GPU memory and gathering batches there")
     ap.add_argument("--save-every", type=int, default=0)
+    ap.add_argument("--text", action="store_true",
+                    help="train the joint graph+text model (gtvae.py) instead of the graph-only step; synthetic "
+                         "graphs then carry synthetic sentences, MRP input needs a 'tokens' id list per graph")
+    ap.add_argument("--vocab", type=int, default=30522, help="vocabulary size of the text branch (bert-base-uncased)")
+    ap.add_argument("--train-graph-recon", action="store_true",
+                    help="joint model: also optimise the graph reconstruction loss (gtvae.py:124 restored)")
     args = ap.parse_args(argv)
 
     rank, local_rank, world = init_process_group()
@@ -163,8 +256,21 @@ def main(argv=None):
         val = prep_data_list(load_mrp(args.dev), args.nodes) if args.dev else []
     else:
         n = args.synthetic or 4096
-        trn = synth_graph_list(n, args.nodes, seed=1234)
-        val = synth_graph_list(max(n // 8, args.batch), args.nodes, seed=4321)
+        vocab = args.vocab if args.text else 0
+        trn = synth_graph_list(n, args.nodes, seed=1234, vocab=vocab)
+        val = synth_graph_list(max(n // 8, args.batch), args.nodes, seed=4321, vocab=vocab)
+    if args.text:
+        from .joint_trainer import JointTrainer
+
+        if any(d.tokens is None for d in trn + val):
+            raise SystemExit("--text needs token ids for every graph ('tokens' in the MRP lines)")
+        trn_loader = DataLoader(trn, args.batch * world, args.nodes)
+        val_loader = DataLoader(val, args.batch, args.nodes) if val else None
+        jt = JointTrainer(args.nodes, args.latent, args.hid, args.nodes, args.vocab, 0, device=dev_, lr=args.lr,
+                          seed=args.seed, train_graph_recon=args.train_graph_recon)
+        gen = torch.Generator().manual_seed(args.seed + rank)
+        return train_joint(trn_loader, val_loader, jt, args.epochs, rank=rank, world=world, generator=gen,
+                           save_every=args.save_every)
     val_loader = DataLoader(val, args.batch, args.nodes) if val else None
     if not args.host_loader:
         from .data import DeviceDataset, DeviceLoader

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""One training step of the joint graph+text model (gtvae.py:95-126 with the
-text branch of text_vae.py) at batch 256: graphs as in the single-GPU graph
-configuration (N=32, d=256), sentences of 8..40 tokens over the 30 522-word
-vocabulary.  Times the step with the HIP projection + cross-entropy
-(DAE.decode_loss) and with that one piece replaced by stock PyTorch
-(Linear + cross_entropy + argmax of softmax), everything else equal."""
+"""Training step of the joint graph+text model (gtvae.py:95-126 with the text branch of text_vae.py,
+BASELINE configs[4]) at batch 256 per GPU: graphs as in the single-GPU graph configuration (N=32, d=256),
+synthetic sentences of 8..40 tokens over the 30 522-word vocabulary, dropout and word noise on.
+
+Runs through JointTrainer (flat parameter / gradient buffers, one gtg_adam_step over every parameter,
+bucketed all-reduce when launched with torchrun), and for comparison (a) the same module stepped by
+torch.optim.Adam, (b) the same with the vocabulary projection + cross-entropy on stock PyTorch.
+
+    python tools/joint_bench.py [steps]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/joint_bench.py [steps]
+"""
 import json
 import os
 import sys
@@ -14,64 +19,79 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 
-from gtg_vae_amd import GTVAE
-from gtg_vae_amd.data import synth_graph_batch
+from gtg_vae_amd.data import collate, synth_graph_list
+from gtg_vae_amd.joint_trainer import JointTrainer
+from gtg_vae_amd.parallel import all_reduce_small, init_process_group, local_device_index
 
 B, N, d, hid, V, T = 256, 32, 256, 512, 30522, 40
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-dev = torch.device("cuda")
-torch.manual_seed(0)
-model = GTVAE(N, d, hid, N, V, 0, text=True).to(dev)
-model.train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.5, 0.999))
-gb = synth_graph_batch(B, N, seed=1234).to(dev)
-g = torch.Generator().manual_seed(7)
-lens = torch.randint(8, T + 1, (B,), generator=g)
-seq = torch.randint(1000, V, (B, T), generator=g)
-seq[:, 0] = 101
-seq[torch.arange(B), lens - 1] = 102
-seq[torch.arange(T)[None, :] >= lens[:, None]] = 0
-seq = seq.to(dev)
-x = gb.dense_x()
+only_trainer = len(sys.argv) > 2 and sys.argv[2] == "trainer"   # just the default-mode trainer (for profiling)
+rank, local_rank, world = init_process_group()
+dev = torch.device("cuda", local_device_index(local_rank))
+torch.cuda.set_device(dev)
+gb = collate(synth_graph_list(B, N, seed=1234 + rank, vocab=V, max_len=T), N).to(dev)
+eps = torch.randn(B, d, generator=torch.Generator().manual_seed(rank)).to(dev)
 
 
-def stock_decode_loss(self, z, input, targets, hidden=None, matrix_mode=None):
-    logits, hidden = self.decode(z, input, hidden)
-    loss = F.cross_entropy(logits.view(-1, logits.size(-1)), targets.flatten(), ignore_index=self.padidx,
-                           reduction="none").view(targets.size())
-    pred = torch.argmax(torch.softmax(logits, 2), 2)
-    return loss, pred, hidden
-
-
-def step():
-    opt.zero_grad(set_to_none=True)
-    res = model(x, gb.edge_index, gb.batch, gb.adj_padded, gb.gold_edges, seq, 0.3)
-    res[0].backward()
-    opt.step()
-    return res
-
-
-def timed():
+def timed(fn):
     for _ in range(3):
-        step()
+        fn()
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
-        res = step()
+        res = fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / steps, float(res[0])
+    ms = e0.elapsed_time(e1) / steps
+    if world > 1:
+        ms = float(all_reduce_small(torch.tensor([ms], device=dev), torch.distributed.ReduceOp.MAX)[0])
+    return ms, float(res)
 
 
-out = {"workload": "joint graph+text step: batch 256, N=32, d=256, T<=40, vocab 30522, dropout and word noise on",
-       "steps": steps, "kept_tokens": int((seq[:, 1:] != 0).sum())}
-for mode in ("bf16x3", "f32", "bf16"):
-    model.graph_vae.encoder.matrix_mode = model.text_vae.matrix_mode = mode
-    ms, loss = timed()
-    out[f"hip_{mode}"] = {"ms_per_step": ms, "graphs_per_s": B / ms * 1e3, "loss": loss}
-model.text_vae.decode_loss = types.MethodType(stock_decode_loss, model.text_vae)
-model.graph_vae.encoder.matrix_mode = model.text_vae.matrix_mode = "bf16x3"
-ms, loss = timed()
-out["stock_projection"] = {"ms_per_step": ms, "graphs_per_s": B / ms * 1e3, "loss": loss}
-print(json.dumps(out))
+out = {"workload": "joint graph+text step: batch 256 per GPU, N=32, d=256, T<=40, vocab 30522, dropout and word noise on",
+       "steps": steps, "n_gpus": world, "kept_tokens": int((gb.dec_seq[:, 1:] != 0).sum())}
+for mode in (("bf16x3",) if only_trainer else ("bf16x3", "f32", "bf16")):
+    tr = JointTrainer(N, d, hid, N, V, 0, device=dev, seed=0, matrix_mode=mode)
+    tr.model.train()
+    ms, loss = timed(lambda: tr.step(gb, gb.dec_seq, eps, 0.3, update=True)["loss"])
+    out[f"trainer_{mode}"] = {"ms_per_step": ms, "graphs_per_s": world * B / ms * 1e3, "loss": loss,
+                              "parameters": tr.numel}
+    if mode != "bf16":
+        del tr
+        torch.cuda.empty_cache()
+
+if world == 1 and not only_trainer:
+    # the same module under torch.optim.Adam (per-tensor foreach kernels) instead of the flat fused step
+    model = tr.model
+    for p in model.parameters():
+        p.grad = None
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+
+    def torch_adam_step():
+        opt.zero_grad(set_to_none=True)
+        res = model(None, gb.edge_index, B, gb.adj_padded, gb.gold_bits, gb.dec_seq, 0.3, eps=eps)
+        res[0].backward()
+        opt.step()
+        return res[0]
+
+    model.graph_vae.encoder.matrix_mode = model.text_vae.matrix_mode = "bf16x3"
+    ms, loss = timed(torch_adam_step)
+    out["torch_adam_bf16x3"] = {"ms_per_step": ms, "graphs_per_s": B / ms * 1e3, "loss": loss}
+
+    def stock_decode_loss(self, z, input, targets, hidden=None, matrix_mode=None):
+        logits, hidden = self.decode(z, input, hidden)
+        loss = F.cross_entropy(logits.view(-1, logits.size(-1)), targets.flatten(), ignore_index=self.padidx,
+                               reduction="none").view(targets.size())
+        pred = torch.argmax(torch.softmax(logits, 2), 2)
+        return loss, pred, hidden
+
+    model.text_vae.decode_loss = types.MethodType(stock_decode_loss, model.text_vae)
+    ms, loss = timed(torch_adam_step)
+    out["torch_adam_stock_projection"] = {"ms_per_step": ms, "graphs_per_s": B / ms * 1e3, "loss": loss}
+if rank == 0:
+    print(json.dumps(out))
+if world > 1:
+    torch.distributed.destroy_process_group()
