@@ -69,7 +69,7 @@ EXPORTS = tuple(_SIGS)
 # operand exactly into three bf16 pieces and runs six products on the bf16 matrix cores with fp32
 # accumulation: the same error as the fp32 pipe at 1.5x its speed, hence the default.
 MATRIX_MODES = {"f32": 0, "bf16": 1, "bf16x3": 3}
-_default_matrix_mode = MATRIX_MODES[os.environ.get("GTG_MATRIX_MODE", "bf16x3")]
+_default_matrix_mode = MATRIX_MODES["bf16x3"]   # changed only through set_default_matrix_mode()
 
 
 def matrix_mode(mode=None) -> int:

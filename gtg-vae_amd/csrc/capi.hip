@@ -523,8 +523,7 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     GemmDesc g;
     // dW2 = dT2c^T * H1c: from the pooled gradient and the winning rows where the shape allows (one aggregated
     // row of H1c per graph and pooled column), else as the dense product
-    static const bool dw2_dense = getenv("GTG_DW2_DENSE") && atoi(getenv("GTG_DW2_DENSE")) != 0;  // experiment hook
-    if (!dw2_dense && dw2_sparse_applies(B, n, d, H)) {
+    if (dw2_sparse_applies(B, n, d, H)) {
         GTG_TRY(dw2_sparse(adj, h1c, H, dpooled, argmax, meta, w.dT2c, B, n, d, w.dw2, dW2, s));
     } else {
         g.A = w.dT2c; g.lda = d; g.a_kc = false;

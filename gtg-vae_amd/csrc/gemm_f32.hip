@@ -755,31 +755,46 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
     }
 
     if (KG == 1 && parts > 1) {
-        // Leave this part's accumulators in its slab (register-major: every store instruction of a wave is
-        // one contiguous 256-byte run); the last part to arrive sums all of them, its own included, in part
-        // order, so the result does not depend on which block that is.  The slab words and the arrival
-        // counter are device-scope relaxed atomics (they go to the point of coherence between the XCDs' L2s
-        // without a whole-cache write-back); a block waits for its own stores to complete before it counts
-        // itself in, so whoever sees the full count can read every slab.
+        // Leave this part's accumulators in its slab; the last part to arrive sums all of them, its own
+        // included, in part order, so the result does not depend on which block that is.
+        // The hand-off between the blocks (they may run on different XCDs, whose L2s are not coherent, and a
+        // CU's vector L1 is never refreshed by another CU's stores):
+        //   writer: every slab byte leaves by a 16-byte WRITE-THROUGH store (buffer_store_dwordx4 sc1: it goes
+        //           to the point of coherence between the XCDs and leaves no dirty L2 line behind, so no cache
+        //           write-back is needed); every storing wave then waits for its stores (vmcnt(0)), the block
+        //           meets at a barrier, and only then one lane counts the block in (device-scope atomic add);
+        //   reader: the block whose add returned parts - 1 knows every other part's stores have completed; one
+        //           lane runs a device-scope acquire (drops this CU's L1 lines), waits for it, the block meets
+        //           at a barrier, and the slabs are read by loads that bypass the L1 as well (sc1).
+        // 16-byte stores: register e of a 32x32 accumulator holds row (e&3) + 8(e>>2) + 4h, so registers
+        // 4q..4q+3 go out as one store; every store instruction of a wave is one contiguous 1 KB run.
         __shared__ int s_last;
-        float* slab0 = a.tail_ws + (long long)tail_tile * parts * (BM * BN);
-        float* mine = slab0 + (long long)part * (BM * BN);
+        const long long slab_off = ((long long)tail_tile * parts) * (BM * BN);
+        const auto slabs = __builtin_amdgcn_make_buffer_rsrc(
+            a.tail_ws + (long long)__builtin_amdgcn_readfirstlane((int)(slab_off >> 8)) * 256, 0,
+            __builtin_amdgcn_readfirstlane(parts) * (BM * BN * 4), 0x00020000);
+        const int mine = part * (BM * BN * 4) + tid * 16;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    __hip_atomic_store(mine + ((i * TN + j) * 16 + e) * GT + tid, acc[i][j][e], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slabs,
+                                                           mine + ((i * TN + j) * 4 + q) * (GT * 16), 0, 16 /* sc1 */);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the block counts itself in
         __syncthreads();
         if (tid == 0) {
             const int seen = __hip_atomic_fetch_add(&a.tail_counters[tail_tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (seen == parts - 1) ? 1 : 0;
-            if (seen == parts - 1)  // ready for the next launch
+            if (seen == parts - 1) {
+                // ready for the next launch
                 __hip_atomic_store(&a.tail_counters[tail_tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed before the barrier opens
+            }
         }
         __syncthreads();
         if (!s_last) return;
@@ -790,20 +805,25 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         for (int p = 0; p < parts; ++p) {
-            const float* src = slab0 + (long long)p * (BM * BN) + tid;
-            f32x16 t[TM][TN];  // all loads of a part in flight before the first add
+            const int src = p * (BM * BN * 4) + tid * 16;
+            f32x4 t[TM][TN][4];  // all loads of a part in flight before the first add
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        t[i][j][e] = __hip_atomic_load(src + ((i * TN + j) * 16 + e) * GT, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
+                    for (int q = 0; q < 4; ++q)
+                        t[i][j][q] = __builtin_bit_cast(
+                            f32x4, __builtin_amdgcn_raw_buffer_load_b128(slabs, src + ((i * TN + j) * 4 + q) * (GT * 16), 0,
+                                                                         16 /* sc1 */));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] += t[i][j];
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += t[i][j][q][e];
         }
     }
 
@@ -1141,8 +1161,7 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
         k.colsum_part = d.colsum_part;
     }
     long long grid = (long long)k.tiles_m * k.tiles_n * splits * d.batch;
-    static const bool tail_off = getenv("GTG_GEMM_TAIL") && atoi(getenv("GTG_GEMM_TAIL")) == 0;  // experiment hook
-    if (!tail_off && d.tail_ws != nullptr && d.tail_counters != nullptr && cfg == CFG_128 && d.batch == 1 && splits == 1 &&
+    if (d.tail_ws != nullptr && d.tail_counters != nullptr && cfg == CFG_128 && d.batch == 1 && splits == 1 &&
         d.epi != EPI_POOL) {
         k.tail_ws = d.tail_ws;
         k.tail_counters = d.tail_counters;
@@ -1216,10 +1235,9 @@ int gemm_pair(const GemmDesc& d0, const GemmDesc& d1, hipStream_t s)
     const bool plain = !p0.empty && !p1.empty && p0.splits == 1 && p1.splits == 1 && p0.k.tail_ws == nullptr &&
                        p1.k.tail_ws == nullptr && p0.grid + p1.grid <= 0x7fffffffLL;
     const bool tn0 = !d0.a_kc && !d0.b_kc, nn1 = d1.a_kc && !d1.b_kc;
-    static const bool pair_off = getenv("GTG_GEMM_PAIR") && atoi(getenv("GTG_GEMM_PAIR")) == 0;  // experiment hook
     // A 64x64 job beside a 32x32 one (the latter over eight wave groups to share the block size) measured
     // slower than the two launches: its LDS leaves one block per CU.
-    if (!(plain && !pair_off && tn0 && nn1 && p0.cfg == CFG_32_K4 && p1.cfg == CFG_32_K4)) {
+    if (!(plain && tn0 && nn1 && p0.cfg == CFG_32_K4 && p1.cfg == CFG_32_K4)) {
         if (int rc = gemm(d0, s)) return rc;
         return gemm(d1, s);
     }

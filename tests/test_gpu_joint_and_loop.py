@@ -91,30 +91,38 @@ def test_named_config_training_step_matches_oracle(name, B, N, d, hid, mode):
 
     params = O.init_params(N, d, hid, N, seed=0)
     tr = GraphVAETrainer(N, d, hid, N, device="cuda", init=params, matrix_mode=mode)
-    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     batch = synth_graph_batch(B, N, seed=1234)
     eps = torch.randn(B, d, generator=torch.Generator().manual_seed(9))
-    loss, rec, kl, _ = O.graph_step_loss(p, None, batch.edge_index, batch.adj_padded, eps, 0.5, B, N)
-    loss.backward()
+
+    def oracle(pool_index=None):
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        loss, rec, kl, _ = O.graph_step_loss(p, None, batch.edge_index, batch.adj_padded, eps, 0.5, B, N, pool_index)
+        loss.backward()
+        return p, rec, kl
+
+    p, rec, kl = oracle()
     for use_graph in (False, True):
         tr.load_state_dict(params)
         res = tr.step(batch.to("cuda"), eps.cuda(), kl_w=0.5, update=False, use_graph=use_graph)
         assert tr.edges_ok()
         assert abs(res["recon"].item() - rec.item()) <= 1e-5 * abs(rec.item())
         assert abs(res["kl"].item() - kl.item()) <= 1e-5 * abs(kl.item()) + 1e-7
-        for k in p:
-            got, want = tr.named_grads()[k], p[k].grad
-            if name != "C":
-                assert _relerr(got, want) < 1e-4, (name, use_graph, k)
-            else:
-                # 512 x 512 max-pools over 64 rows: a few dozen winners lead the runner-up by less than 1e-6
-                # relative, and whichever side of such a tie a rounding error falls on moves 1/512 of one
-                # column's gradient to another row (measured: one such flip between the two matrix modes, 2e-4 of
-                # the largest entry).  So the entry-wise bound is looser here and the norm-wise one carries the
-                # check: a flip touches one column of dW2 and two rows of dZ1, real error would touch everything.
-                assert _relerr(got, want) < 1e-3, (name, use_graph, k)
-                g64, w64 = got.detach().double().cpu(), want.detach().double().cpu()
-                assert ((g64 - w64).norm() / w64.norm()).item() < 1e-4, (name, use_graph, k)
+        # The max-pool's winners against the oracle's.  Where two rows of a graph tie to within rounding the two
+        # implementations may pick different ones, and each such flip moves one graph's share of one column's
+        # gradient to another row.  A flip is legitimate only on such a tie, and only a handful may occur; the
+        # gradients are then compared with the oracle routed through the same winners, at the same 1e-4.
+        with torch.no_grad():
+            _, nodes = O.encode(params, None, batch.edge_index, B, N, return_nodes=True)
+        won = tr.argmax[:B].long().cpu()
+        top2 = nodes.topk(min(2, N), dim=1).values
+        flipped = (nodes.gather(1, won.view(B, 1, d)).squeeze(1) != top2[:, 0]).nonzero()
+        assert len(flipped) <= 8, (name, mode, len(flipped))
+        for b, c in flipped.tolist():
+            lead = (top2[b, 0, c] - nodes[b, won[b, c], c]).abs().item()
+            assert lead <= 1e-6 * max(abs(top2[b, 0, c].item()), 1e-30), (name, mode, b, c, lead)
+        want = oracle(won)[0] if len(flipped) else p
+        for k in want:
+            assert _relerr(tr.named_grads()[k], want[k].grad) < 1e-4, (name, mode, use_graph, k)
 
 
 def test_train_and_dev_loop_runs_and_learns(capsys):

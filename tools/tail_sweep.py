@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the row-ragged 128x128 GEMM as a function of the device-side row count
-(tiles per round of resident blocks); GTG_GEMM_TAIL=0 turns the tail split off."""
+(tiles per round of resident blocks)."""
 import os
 import sys
 
