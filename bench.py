@@ -43,13 +43,22 @@ def flops_per_graph_fwd(N, d, h):
     return 4 * N * N * d + 4 * N * d * d + 2 * N * N * d + 4 * d * d + 2 * d * h + 2 * h * M
 
 
+def host_cores():
+    """Every core this job may use: OMP_NUM_THREADS where the launcher sets it (a one-GPU share of a big
+    host), else the process's CPU affinity."""
+    env = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if env > 0:
+        return env
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
 def cpu_baseline(N, B, d, hid, budget_s=20.0):
     """The oracle's training step (scatter GCN as PyG does it, autograd, Adam)
     on the host cores: >=3 warm-up steps, then timed steps until the budget."""
     from gtg_vae_amd.data import synth_graph_batch
     from oracle import graphvae_oracle as O
 
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    threads = host_cores()
     torch.set_num_threads(threads)
     params = {k: v.clone().requires_grad_(True) for k, v in O.init_params(N, d, hid, N, seed=0).items()}
     opt = torch.optim.Adam(list(params.values()), lr=1e-3, betas=(0.5, 0.999))
@@ -75,8 +84,9 @@ def cpu_baseline(N, B, d, hid, budget_s=20.0):
     times.sort()
     med = times[len(times) // 2]
     return {"value": B / med, "unit": "graphs/s", "cores": threads, "kind": "port",
-            "sample": "%d timed steps of the same workload (B=%d, N=%d, d=%d), median step %.1f ms; oracle = eager "
-                      "PyTorch-CPU scatter-GCN step with autograd + Adam" % (len(times), B, N, d, med * 1e3)}
+            "sample": "%d timed steps of the same workload (B=%d, N=%d, d=%d), median step %.1f ms, on every core this "
+                      "job may use; oracle = eager PyTorch-CPU scatter-GCN step with autograd + Adam" % (
+                          len(times), B, N, d, med * 1e3)}
 
 
 def mst_cpu_baseline(rows_host, N):
@@ -94,8 +104,7 @@ def mst_cpu_baseline(rows_host, N):
                      "(the reference's own Python takes ~61 ms per graph at N=64)" % (n, dt * 1e3)}
     # the same code on every core this process may use: graphs are independent, ctypes releases the GIL
     from concurrent.futures import ThreadPoolExecutor
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+    cores = host_cores()
     per = 2048
     total = min(len(rows_host), cores * per)
     chunks = [rows_host[i:i + per] for i in range(0, total, per)]
@@ -106,6 +115,66 @@ def mst_cpu_baseline(rows_host, N):
     res["all_cores"] = {"value": total / dt, "unit": "graphs/s", "cores": cores,
                         "sample": "%d rows in chunks of %d over a pool of %d threads, %.1f ms" % (total, per, cores, dt * 1e3)}
     return res
+
+
+PMC_FILE = "profiles/r02_pmc_traffic.json"
+PMC_SOURCE_NOTE = ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes over this "
+                   "launch shape, committed as %s; NOT measured in this run (null: no pass on record)" % PMC_FILE)
+
+
+def pmc_traffic(key):
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            return json.load(f).get(key, {}).get("traffic_bytes")
+    except OSError:
+        return None
+
+
+def small_config_bench(dev, N, B, d, hid, steps=100):
+    """A short run of another named configuration (HIP-graph replay, resident inputs), for the sub-records."""
+    from gtg_vae_amd.data import synth_graph_batch
+    from gtg_vae_amd.trainer import GraphVAETrainer
+
+    tr = GraphVAETrainer(N, d, hid, N, device=dev, seed=0, max_batch=B, max_edges=B * N * 4)
+    batches = [synth_graph_batch(B, N, seed=77 + i).to(dev) for i in range(2)]
+    eps = [torch.randn(B, d, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(2)]
+    tr.set_kl_weight(0.5)
+    for i in range(10):
+        tr.load_batch(batches[i % 2], eps[i % 2])
+        tr.run_loaded(update=True, use_graph=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.load_batch(batches[i % 2], eps[i % 2])
+        tr.run_loaded(update=True, use_graph=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "synthetic graphs N<=%d, batch %d, d=%d, mlp_hid=%d, graph-only step" % (N, B, d, hid),
+            "ms_per_step": dt * 1e3, "graphs_per_s": B / dt}
+
+
+def joint_bench(dev, steps=8):
+    """BASELINE configs[4] on one GPU: the joint graph+text step through JointTrainer (batch 256, N=32, d=256,
+    sentences of 8..40 tokens, vocabulary 30 522, dropout and word noise on)."""
+    from gtg_vae_amd.data import collate, synth_graph_list
+    from gtg_vae_amd.joint_trainer import JointTrainer
+
+    B, N, d, hid, V, T = 256, 32, 256, 512, 30522, 40
+    gb = collate(synth_graph_list(B, N, seed=1234, vocab=V, max_len=T), N).to(dev)
+    eps = torch.randn(B, d, generator=torch.Generator().manual_seed(0)).to(dev)
+    tr = JointTrainer(N, d, hid, N, V, 0, device=dev, seed=0)
+    tr.model.train()
+    for _ in range(3):
+        tr.step(gb, gb.dec_seq, eps, 0.3, update=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(gb, gb.dec_seq, eps, 0.3, update=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "configs[4] on one GPU: joint graph+text step, batch 256, N=32, d=256, T<=40, vocab 30522; "
+                        "HIP graph half + HIP vocabulary projection/cross-entropy + flat fused Adam, stock LSTMs",
+            "ms_per_step": dt * 1e3, "graphs_per_s": B / dt, "parameters": tr.numel}
 
 
 def mst_bench(device, G=65536, N=64, reps=5, cpu=True):
@@ -131,16 +200,11 @@ def mst_bench(device, G=65536, N=64, reps=5, cpu=True):
     ms = rep[0][5] / rep[0][4]
     bytes_per_graph = 4 * M + 4 * (2 * (N - 1) + 1)
     gbps = G * bytes_per_graph / (ms * 1e-3) / 1e9
-    traffic = None  # HBM bytes per launch from the committed PMC passes (same shape only)
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
-            traffic = json.load(f).get("mst_triu %d %d" % (G, N), {}).get("traffic_bytes")
-    except OSError:
-        pass
+    traffic = pmc_traffic("mst_triu %d %d" % (G, N))
     res = {"workload": "configs[3]: %d graphs, N=%d, upper-triangular fp32 rows" % (G, N),
            "graphs_per_s": G / (ms * 1e-3), "ms": ms,
            "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic,
+                        "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic, "traffic_source": PMC_SOURCE_NOTE,
                         "algorithmic_bytes_per_graph": bytes_per_graph}}
     if cpu:
         res["cpu_baseline"] = mst_cpu_baseline(rows_host, N)
@@ -160,6 +224,7 @@ def main():
                     help="strong scaling: --batch is the global batch, split evenly over the GPUs (default: weak, --batch per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mst", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sub-records of configurations A, B and the joint step")
     ap.add_argument("--matrix", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
                     help="matrix pipe of the large encoder GEMMs: fp32 MFMA; the exact three-way bf16 split on the bf16 "
                          "MFMA (fp32-level error, default); plain bf16 operands (loss tolerance 1e-3)")
@@ -248,6 +313,11 @@ def main():
         torch.cuda.synchronize()
     prof = _lib.profile_report()
     _lib.profile_enable(False)
+    # kernel launches of one step (the library counts its launches on the host)
+    c0 = _lib.lib().gtg_launch_count()
+    one_step(0, graph=False)
+    torch.cuda.synchronize()
+    launches_per_step = int(_lib.lib().gtg_launch_count() - c0)
     if not tr.edges_ok():
         raise SystemExit("adjacency kernel flagged an invalid edge list")
     recon, kl = tr.scalars[0].item(), tr.scalars[1].item()
@@ -283,19 +353,14 @@ def main():
             avg_ms = tot_ms / cnt
             ach = fl / (avg_ms * 1e-3) / 1e12
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (bench.py cannot read PMCs itself)
-            traffic = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                    traffic = json.load(f).get("%s %s %d %d %d" % (args.matrix, name, m_, n_, k_), {}).get("traffic_bytes")
-            except OSError:
-                pass
+            traffic = pmc_traffic("%s %s %d %d %d" % (args.matrix, name, m_, n_, k_))
             # the 128x128 GEMMs run on the pipe --matrix selects: price them against that pipe's peak, counting the
             # MFMA products actually issued (six per multiply-add for the three-way split)
             on_bf16 = args.matrix != "f32" and name.startswith("gemm128")
             peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_F32_MFMA_TFLOPS
             issued = ach * (MODE_PRODUCTS[args.matrix] if on_bf16 else 1)
             roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s",
-                    "frac": issued / peak, "traffic": traffic, "kernel": name,
+                    "frac": issued / peak, "traffic": traffic, "traffic_source": PMC_SOURCE_NOTE, "kernel": name,
                     "pipe": ("v_mfma_f32_32x32x16_bf16, %d products per fp32 multiply-add" % MODE_PRODUCTS[args.matrix])
                             if on_bf16 else "v_mfma_f32_32x32x2_f32",
                     "fp32_equivalent_tflops": ach,
@@ -308,7 +373,9 @@ def main():
                                    "%d eager steps right after the timed graph replays" % prof_steps)}}
             for r in sorted(big, key=lambda r: -r[5])[:8]:
                 kern["%s M%d N%d K%d" % r[:4]] = {"avg_ms": r[5] / r[4], "tflops": executed_flops(r) / (r[5] / r[4] * 1e-3) / 1e12}
-        step_tflops = value * 3 * F / 1e12
+        # FLOPs the step's GEMM launches executed (the sparse row-product kernels of the encoder, which replace
+        # dense products of the padded formula, and the element-wise kernels are not counted), per step and GPU
+        gemm_flops = sum(executed_flops(r) * r[4] for r in big) / prof_steps
         line = {
             "metric": ("training graphs/sec (whole node) at N=64 nodes, batch 512; 1/2/4/8 MI355X"
                        if (N, (world * B if args.strong else B), d, hid) == (64, 512, 512, 512) else
@@ -327,8 +394,13 @@ def main():
                                                  "parity tests run at the fp32 tolerances in this mode)",
                                        "bf16": "large encoder GEMMs on bf16-rounded operands, fp32 accumulation "
                                                "(loss tolerance 1e-3)"}[args.matrix]},
-            "step_algorithmic_tflops": step_tflops,
-            "step_frac_of_f32_mfma_peak": step_tflops / (PEAK_F32_MFMA_TFLOPS * world),
+            "step_executed": {"gemm_gflop_per_step": gemm_flops / 1e9,
+                              "gemm_tflops_over_whole_step": gemm_flops / (ms_per_step * 1e-3) / 1e12,
+                              "frac_of_f32_mfma_peak": gemm_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                              "padded_formula_gflop_per_step": 3 * F * B / 1e9,
+                              "launches_per_step": launches_per_step,
+                              "note": "executed multiply-adds of the GEMM launches only, as fp32 FLOPs, over the step time; "
+                                      "the padded formula counts rows and dense products the compact-row encoder skips"},
             "encoder_rows": {"padded": B * N, "stored_mean": eff_rows},
             "loss": {"recon": recon, "kl": kl},
             "roofline": roof,
@@ -356,6 +428,12 @@ def main():
             line["other_matrix_modes"] = alt
         if world == 1 and not args.no_mst:
             line["mst"] = mst_bench(dev, cpu=not args.no_cpu_baseline)
+        if world == 1 and not args.no_extra:
+            del tr
+            torch.cuda.empty_cache()
+            line["config_b"] = small_config_bench(dev, 32, 256, 256, 512)
+            line["config_a"] = small_config_bench(dev, 10, 64, 32, 512)
+            line["joint"] = joint_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(N, B, d, hid)
             line["cpu_baseline"] = cb

@@ -23,6 +23,7 @@ _SIGS = {
     "gtg_version": (c_int, []),
     "gtg_last_error": (ctypes.c_char_p, []),
     "gtg_max_nodes": (c_int, []),
+    "gtg_launch_count": (c_int64, []),
     "gtg_profile_enable": (c_int, [c_int]),
     "gtg_profile_report": (c_int64, [ctypes.c_char_p, c_size_t]),
     "gtg_mst_batched_triu": (c_int, [_P, c_int64, c_int, _P, _P, _P]),

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -31,8 +32,11 @@ int set_error(int code, const char* fmt, ...)
     return code;
 }
 
+static std::atomic<long long> g_launches{0};
+
 int check_launch(const char* what)
 {
+    g_launches.fetch_add(1, std::memory_order_relaxed);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(GTG_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return GTG_OK;
@@ -122,6 +126,8 @@ int gtg_version(void) { return GTG_VERSION; }
 const char* gtg_last_error(void) { return g_err; }
 
 int gtg_max_nodes(void) { return 64; }
+
+int64_t gtg_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
 
 // Timing of the GEMM and MST launches with HIP events on the caller's stream.
 // Not for use under graph capture.  gtg_profile_report writes one line per
@@ -234,7 +240,8 @@ int gtg_encoder_fwd(const float* adj, const float* x, const float* W1, const flo
     GTG_REQUIRE(x != nullptr || f == n, "identity node features need input_dim == n");
     if (num_graphs == 0) return GTG_OK;
     GTG_REQUIRE(adj && W1 && b1 && W2 && b2 && h1 && pooled && argmax, "null pointer");
-    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4, "batch too large");
+    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4 && num_graphs <= GTG_MAX_GRAPHS_PER_CALL,
+                "batch too large (at most 65000 graphs per call)");
     hipStream_t s = (hipStream_t)stream;
     const int B = (int)num_graphs, H = 2 * d, rows = B * n;
     Carver c(ws, ws_bytes);
@@ -321,7 +328,8 @@ int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const flo
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
     GTG_REQUIRE(x != nullptr || f == n, "identity node features need input_dim == n");
     GTG_REQUIRE(adj && W2 && h1 && argmax && dpooled && dW1 && db1 && dW2 && db2, "null pointer");
-    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4, "batch too large");
+    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4 && num_graphs <= GTG_MAX_GRAPHS_PER_CALL,
+                "batch too large (at most 65000 graphs per call)");
     hipStream_t s = (hipStream_t)stream;
     const int B = (int)num_graphs, H = 2 * d, rows = B * n;
     Carver c(ws, ws_bytes);
@@ -418,7 +426,8 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const floa
     GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
     GTG_REQUIRE(adj && extents && W1 && b1 && W2 && b2 && meta && adjc && h1c && pooled && argmax, "null pointer");
-    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4, "batch too large");
+    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4 && num_graphs <= GTG_MAX_GRAPHS_PER_CALL,
+                "batch too large (at most 65000 graphs per call)");
     hipStream_t s = (hipStream_t)stream;
     const int B = (int)num_graphs, H = 2 * d, rows = B * n + n;
     Carver c(ws, ws_bytes);
@@ -510,6 +519,8 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
     GTG_REQUIRE(adj && adjc && meta && W2 && h1c && argmax && dpooled && dW1 && db1 && dW2 && db2, "null pointer");
+    GTG_REQUIRE((int64_t)num_graphs * n < (1ll << 31) / 4 && num_graphs <= GTG_MAX_GRAPHS_PER_CALL,
+                "batch too large (at most 65000 graphs per call)");
     hipStream_t s = (hipStream_t)stream;
     const int B = (int)num_graphs, H = 2 * d, rows = B * n + n;
     Carver c(ws, ws_bytes);

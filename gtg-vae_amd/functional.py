@@ -4,12 +4,27 @@ PyTorch is used for device memory, streams and the autograd graph only; every
 arithmetic step of forward and backward runs in csrc/*.hip.  All tensors must
 be fp32 and on the GPU; there is no fallback.
 """
+import functools
 from typing import Optional
 
 import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
+
+
+def _on_tensor_device(fn):
+    """Run ``fn`` with the device of its first GPU tensor argument current, so that the stream handed to the
+    library (the current stream) and the kernels' launch device are the tensors' device even when the caller's
+    current device is another GPU."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = next((a.device for a in args if torch.is_tensor(a) and a.is_cuda), None)
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -28,6 +43,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 # adjacency
 # ---------------------------------------------------------------------------
+@_on_tensor_device
 def build_adj(edge_index: torch.Tensor, num_graphs: int, nmax: int, check_edges: bool = False,
               return_extents: bool = False):
     """D^-1/2 (C + I) D^-1/2 per graph, (B, nmax, nmax) fp32, from a PyG-style
@@ -59,6 +75,7 @@ class EncoderFn(torch.autograd.Function):
     """pooled (B, d) = global_max_pool(GCN2(relu(GCN1(x))))."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, adj, x, W1, b1, W2, b2, extents=None, matrix_mode=None):
         L = _lib.lib()
         ctx.mode = mode = _lib.matrix_mode(matrix_mode)
@@ -100,6 +117,7 @@ class EncoderFn(torch.autograd.Function):
         return pooled, argmax
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dpooled, _dargmax):
         L = _lib.lib()
         B, n, f, d = ctx.dims
@@ -134,6 +152,7 @@ class LatentFn(torch.autograd.Function):
     inspection only (non-differentiable outputs)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, h, Wmu, bmu, Wlv, blv, eps):
         L = _lib.lib()
         h, Wmu, bmu, Wlv, blv, eps = map(_f32c, (h, Wmu, bmu, Wlv, blv, eps))
@@ -151,6 +170,7 @@ class LatentFn(torch.autograd.Function):
         return z, kl, mu, lv
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dz, dkl, _dmu, _dlv):
         L = _lib.lib()
         h, Wmu, Wlv, mu, lv, eps = ctx.saved_tensors
@@ -175,6 +195,7 @@ class ReparamKLFn(torch.autograd.Function):
     """(z, kl) from (mu, logvar, eps): GTVAE.reparameterize + GTVAE.loss_kl."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, mu, logvar, eps):
         L = _lib.lib()
         mu, logvar, eps = map(_f32c, (mu, logvar, eps))
@@ -188,6 +209,7 @@ class ReparamKLFn(torch.autograd.Function):
         return z, kl
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dz, dkl):
         L = _lib.lib()
         mu, logvar, eps = ctx.saved_tensors
@@ -208,6 +230,7 @@ class DecoderFn(torch.autograd.Function):
     """out (B, M) = sigmoid(relu(z D1^T + c1) D2^T + c2)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, z, D1, c1, D2, c2):
         L = _lib.lib()
         z, D1, c1, D2, c2 = map(_f32c, (z, D1, c1, D2, c2))
@@ -222,6 +245,7 @@ class DecoderFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, dout):
         L = _lib.lib()
         z, D1, D2, y1, out = ctx.saved_tensors
@@ -245,6 +269,7 @@ class BCELossFn(torch.autograd.Function):
     """mean_b mean_k BCE(out[b,k], triu(adj[b])[k]) (log clamped at -100)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, out, adj):
         L = _lib.lib()
         out, adj = _f32c(out), _f32c(adj)
@@ -260,6 +285,7 @@ class BCELossFn(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g):
         L = _lib.lib()
         out, adj = ctx.saved_tensors
@@ -271,6 +297,7 @@ class BCELossFn(torch.autograd.Function):
         return dout, None
 
 
+@_on_tensor_device
 def edge_precision_recall(edges: torch.Tensor, count: torch.Tensor, gold_bits: torch.Tensor, nmax: int):
     """Per-graph (recall, precision) fp32 tensors on the GPU."""
     _lib.require_cuda(edges, count, gold_bits)
@@ -282,6 +309,7 @@ def edge_precision_recall(edges: torch.Tensor, count: torch.Tensor, gold_bits: t
     return rec, prec
 
 
+@_on_tensor_device
 def gemm(A, B, a_kc=True, b_kc=True, bias=None, epilogue=0, aux=None, out=None, M=None, N=None, K=None,
          split_k=True, matrix_mode="f32"):
     """Thin test/profiling hook over gtg_gemm_f32 (see include/gtgvae.h)."""
@@ -301,6 +329,7 @@ def gemm(A, B, a_kc=True, b_kc=True, bias=None, epilogue=0, aux=None, out=None, 
     return C
 
 
+@_on_tensor_device
 def gemm_rows(A, B, a_kc=True, b_kc=True, rows_dev=None, bias=None, epilogue=0, aux=None, out=None, matrix_mode="f32"):
     """Test/profiling hook over gtg_gemm_f32_rows: the GEMM of the compact-row
     encoder (row count read on the device, tail tiles split along K)."""
@@ -330,6 +359,7 @@ class ProjCEFn(torch.autograd.Function):
     all three GEMMs."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, H, W, b, targets, padidx, matrix_mode=None):
         L = _lib.lib()
         ctx.mode = mode = _lib.matrix_mode(matrix_mode)
@@ -357,6 +387,7 @@ class ProjCEFn(torch.autograd.Function):
         return loss, pred
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, gloss, _gpred):
         L = _lib.lib()
         W, rowmap, Hc, P = ctx.saved_tensors

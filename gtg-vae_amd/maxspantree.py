@@ -43,7 +43,8 @@ def mst_graph_batched(x: torch.Tensor, nmax: int = None) -> Tuple[torch.Tensor, 
     edges = torch.empty((G, max(n - 1, 0), 2), dtype=torch.int32, device=x.device)
     count = torch.empty((G,), dtype=torch.int32, device=x.device)
     if G > 0:
-        _lib.check(fn(_lib.ptr(x), G, n, _lib.ptr(edges), _lib.ptr(count), _lib.stream_ptr()), "mst_graph_batched")
+        with torch.cuda.device(x.device):   # launch on x's GPU even if another one is current
+            _lib.check(fn(_lib.ptr(x), G, n, _lib.ptr(edges), _lib.ptr(count), _lib.stream_ptr()), "mst_graph_batched")
     return edges, count
 
 

@@ -14,7 +14,8 @@
  *   - dense matrices are row-major fp32; indices are int32 unless stated;
  *   - return 0 on success, a negative GTG_ERR_* code otherwise, with a
  *     human-readable message in gtg_last_error() (thread-local);
- *   - n (nodes per padded graph) must be in [1, 64];
+ *   - n (nodes per padded graph) must be in [1, 64]; the encoder entry points take
+ *     at most GTG_MAX_GRAPHS_PER_CALL graphs per call (larger batches: several calls);
  *   - *_workspace_bytes() return the exact size the matching call carves;
  *     pass a buffer at least that large (256-byte aligned).
  *   - all reductions are ordered: identical inputs give bit-identical outputs.
@@ -48,6 +49,9 @@ extern "C" {
  *                      at 1.5x its speed.  Inf operands give NaN (inf - inf in the split).
  *   GTG_MATRIX_BF16    operands rounded to bf16 (round to nearest even), one product:
  *                      about 3e-3 of max|C|; for loss tolerances of 1e-3. */
+/* The encoder entry points launch one grid row per graph: at most this many graphs per call. */
+#define GTG_MAX_GRAPHS_PER_CALL 65000
+
 #define GTG_MATRIX_F32 0
 #define GTG_MATRIX_BF16 1
 #define GTG_MATRIX_BF16X3 3
@@ -55,6 +59,9 @@ extern "C" {
 int gtg_version(void);
 const char* gtg_last_error(void);
 int gtg_max_nodes(void);
+/* Kernel launches issued by the library in this process so far (a host-side counter for benchmarks:
+ * the difference around one eager step is the step's launch count). */
+int64_t gtg_launch_count(void);
 
 /* Optional timing of the GEMM and MST kernel launches with HIP event pairs on
  * the caller's stream (used by bench.py for the roofline figures; the only
