@@ -61,6 +61,8 @@ _SIGS = {
     "gtg_gemm_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, c_int, _P, c_int, _P, c_size_t, c_int, _P]),
     "gtg_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gtg_gemm_rows_workspace_bytes": (c_size_t, []),
+    "gtg_split_planes": (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),
+    "gtg_gemm_planes_rows": (c_int, [_P, _P, _P] + [c_int] * 4 + [_P, c_int, _P, c_int, _P, _P, c_size_t, _P]),
     "gtg_gemm_f32_rows": (c_int, [_P] * 3 + [c_int] * 8 + [_P, c_int, _P, c_int, _P, c_int, _P, c_size_t, _P]),
 }
 

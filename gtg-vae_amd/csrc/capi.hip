@@ -478,6 +478,8 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const floa
 
 struct EncCBwdWs {
     float *dT2c, *dZ1c, *pg, *cs, *slabs, *tail, *dw2;
+    float* proto_rows;   // plane path: the prototype rows' gradient as fp32
+    void* w2t_planes;    // plane path: W2^T as k-blocked bf16 planes
     int32_t* tail_cnt;
     size_t tail_cnt_count;
 };
@@ -486,7 +488,10 @@ static void enc_cbwd_layout(Carver& c, int64_t B, int n, int d, EncCBwdWs* w)
 {
     const size_t rows = (size_t)B * n + n;
     const int H = 2 * d;
-    w->dT2c = c.take<float>(rows * d);
+    // fp32 rows, or (GTG_MATRIX_BF16X3, plane path) three bf16 planes: sized for the larger
+    w->dT2c = reinterpret_cast<float*>(c.take<char>(rows * d * 6));
+    w->proto_rows = c.take<float>((size_t)n * d);
+    w->w2t_planes = c.take<char>((size_t)d * H * 6);
     w->dZ1c = c.take<float>(rows * H);
     w->pg = reinterpret_cast<float*>(c.take<char>(proto_grad_workspace(n, d)));
     w->cs = reinterpret_cast<float*>(c.take<char>(max2(max2(colsum_workspace(B, d), colsum_workspace((int64_t)rows, H)),
@@ -529,13 +534,23 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_encoder_compact_bwd: workspace too small");
     const int32_t* all_rows = meta + 2 * B + 1;  // R + n
 
+    // The plane path: in the BF16X3 mode, at sizes where dZ1c = (dT2c W2) masked runs on the 128x128 tiles and dW2
+    // needs no fp32 dT2c, the gather writes dT2c straight as the three bf16 planes that GEMM consumes, W2^T is split
+    // once, and the GEMM's loop carries no split arithmetic.
+    const bool planes = matrix_mode == GTG_MATRIX_BF16X3 && pool_bwd_gather_planes_applies(n, d) && dw2_sparse_applies(B, n, d, H) &&
+                        (long long)((rows + 127) / 128) * ((H + 127) / 128) >= 192;
     // dT2c: real rows from the max-pool routing, prototype rows from the graphs whose maximum they won
-    GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, w.pg, w.tail_cnt, (int)w.tail_cnt_count, s));
+    if (planes) {
+        GTG_TRY(pool_bwd_gather_planes(adj, dpooled, argmax, meta, B, n, d, rows, w.dT2c, w.proto_rows, w.pg, w.tail_cnt,
+                                       (int)w.tail_cnt_count, W2, d, H, H, w.w2t_planes, s));
+    } else {
+        GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, w.pg, w.tail_cnt, (int)w.tail_cnt_count, s));
+    }
     GemmDesc g;
     // dW2 = dT2c^T * H1c: from the pooled gradient and the winning rows where the shape allows (one aggregated
     // row of H1c per graph and pooled column), else as the dense product
     if (dw2_sparse_applies(B, n, d, H)) {
-        GTG_TRY(dw2_sparse(adj, h1c, H, dpooled, argmax, meta, w.dT2c, B, n, d, w.dw2, dW2, s));
+        GTG_TRY(dw2_sparse(adj, h1c, H, dpooled, argmax, meta, w.dT2c, planes ? w.proto_rows : nullptr, B, n, d, w.dw2, dW2, s));
     } else {
         g.A = w.dT2c; g.lda = d; g.a_kc = false;
         g.B = h1c; g.ldb = H; g.b_kc = false;
@@ -545,8 +560,14 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     }
     // dZ1c = (dT2c * W2) masked by relu
     g = GemmDesc();
-    g.A = w.dT2c; g.lda = d; g.a_kc = true;
-    g.B = W2; g.ldb = H; g.b_kc = false;
+    if (planes) {
+        g.planes = true;
+        g.A = w.dT2c; g.lda = rows; g.planeA = (long long)d * rows;
+        g.B = reinterpret_cast<const float*>(w.w2t_planes); g.ldb = H; g.planeB = (long long)d * H;
+    } else {
+        g.A = w.dT2c; g.lda = d; g.a_kc = true;
+        g.B = W2; g.ldb = H; g.b_kc = false;
+    }
     g.C = w.dZ1c; g.ldc = H; g.M = rows; g.N = H; g.K = d; g.m_dev = all_rows;
     g.epi = EPI_MASK; g.aux = h1c; g.ldaux = H;
     g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
@@ -897,6 +918,35 @@ int gtg_gemm_f32_rows(const float* A, const float* B, float* C, int M, int N, in
     GemmDesc g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_kc = a_kc != 0; g.b_kc = b_kc != 0; g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux;
+    g.m_dev = rows_dev;
+    g.tail_ws = reinterpret_cast<float*>(ws);
+    g.tail_counters = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + tb);
+    GTG_TRY(clear_i32(g.tail_counters, (int64_t)(cb / sizeof(int32_t)), (hipStream_t)stream));
+    return gemm(g, (hipStream_t)stream);
+}
+
+// The three-plane split and the GEMM on operands that arrive split (tests and profiling).
+int gtg_split_planes(const float* src, int64_t rows, int64_t cols, int64_t ld, int transpose, void* planes, void* stream)
+{
+    GTG_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, "bad size");
+    GTG_REQUIRE((transpose ? rows : cols) % 16 == 0, "the operand's depth must be a multiple of 16");
+    GTG_REQUIRE(rows * cols == 0 || (src && planes), "null pointer");
+    return split_planes(src, rows, cols, ld, transpose != 0, planes, (hipStream_t)stream);
+}
+
+int gtg_gemm_planes_rows(const void* A_planes, const void* B_planes, float* C, int M, int N, int K, int ldc,
+                         const float* bias, int epilogue, const float* aux, int ldaux, const int32_t* rows_dev, void* ws,
+                         size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_ACCUM, "unsupported epilogue");
+    size_t tb, cb;
+    gemm_tail_workspace(&tb, &cb);
+    GTG_REQUIRE(ws != nullptr && ws_bytes >= tb + cb, "workspace too small");
+    GemmDesc g;
+    g.A = reinterpret_cast<const float*>(A_planes); g.B = reinterpret_cast<const float*>(B_planes); g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = M; g.ldb = N; g.ldc = ldc;
+    g.planes = true; g.planeA = (long long)M * K; g.planeB = (long long)N * K;
+    g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux;
     g.m_dev = rows_dev;
     g.tail_ws = reinterpret_cast<float*>(ws);
     g.tail_counters = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + tb);

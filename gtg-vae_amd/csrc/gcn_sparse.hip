@@ -256,7 +256,8 @@ __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* 
                                                                 int ldh, const float* __restrict__ dpool,
                                                                 const int32_t* __restrict__ argmax,
                                                                 const int32_t* __restrict__ meta,
-                                                                const float* __restrict__ dT2c, int B, int n, int d,
+                                                                const float* __restrict__ dT2c,
+                                                                const float* __restrict__ proto_rows, int B, int n, int d,
                                                                 float* __restrict__ partial)
 {
     __shared__ float Hs[64 * DW_LD];
@@ -315,7 +316,9 @@ __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* 
             p.a[t] = keep_if(A[min(j, n - 1) * n], j < nb && lane < nb);
         }
         const int am = argmax[(long long)b * d + cc];
-        const float* gsrc = proto ? dT2c + (long long)off * d : dpool + (long long)b * d;
+        // a prototype row's gradient: row off of dT2c, or row off - R of a separate (n, d) block
+        const float* gsrc = proto ? (proto_rows ? proto_rows + (long long)(off - R) * d : dT2c + (long long)off * d)
+                                  : dpool + (long long)b * d;
         const bool real = proto || (am >= 0 && am < nb);
         p.g = keep_if(gsrc[cc], c_ok && real);
         p.am = proto ? off - R : (real ? am : 0);
@@ -444,14 +447,15 @@ bool dw2_sparse_applies(int64_t B, int n, int d, int H)
 size_t dw2_sparse_workspace(int d, int H) { return (size_t)DW_GROUPS * d * H * sizeof(float); }
 
 int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, const int32_t* argmax, const int32_t* meta,
-               const float* dT2c, int64_t B, int n, int d, float* partial, float* dW2, hipStream_t s)
+               const float* dT2c, const float* proto_rows, int64_t B, int n, int d, float* partial, float* dW2,
+               hipStream_t s)
 {
     if (!dw2_sparse_applies(B, n, d, H)) return set_error(GTG_ERR_INVALID, "dw2_sparse: shape not supported");
     if ((reinterpret_cast<uintptr_t>(partial) & 15) != 0 || (reinterpret_cast<uintptr_t>(dW2) & 15) != 0)
         return set_error(GTG_ERR_INVALID, "dw2_sparse: outputs must be 16-byte aligned");
     ProfScope prof(s, "dw2_sparse", B * n, H, d);
     hipLaunchKernelGGL(dw2_sparse_kernel, dim3(H / DW_COLS, DW_GROUPS, (d + DW_CPB - 1) / DW_CPB), dim3(DW_THREADS), 0, s,
-                       adj, h1c, H, dpool, argmax, meta, dT2c, (int)B, n, d, partial);
+                       adj, h1c, H, dpool, argmax, meta, dT2c, proto_rows, (int)B, n, d, partial);
     if (int rc = check_launch("dw2_sparse_kernel")) return rc;
     hipLaunchKernelGGL(dw2_reduce_kernel, dim3((d + 31) / 32, (H + 31) / 32), dim3(256), 0, s, partial, d, H, dW2);
     return check_launch("dw2_reduce_kernel");

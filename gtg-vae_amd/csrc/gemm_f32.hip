@@ -53,6 +53,9 @@ struct KArgs {
     int32_t* tail_counters; // arrivals per tail tile
     int tail_slots;         // resident block slots of the device for this kernel
     float* colsum_part;     // optional: column sums of C per wave row-block, (tiles_m * WAVES_M, N)
+    // PREC 4: A and B point at bf16 plane images [3][K/16][rows][16]; lda / ldb are then the `rows` extents of the
+    // images and these the distances between planes, in bf16 elements
+    long long planeA, planeB;
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).
@@ -329,6 +332,26 @@ struct TileB {
     }
 };
 
+// Operands that arrive already split: three bf16 planes per operand, made once by split_planes_kernel (weights)
+// or written that way by the kernel that produces the operand, in the k-blocked layout
+//     [plane][K / 16][rows][16]   (bf16)
+// so that the 16 k values of one k step of ALL rows of a tile are one contiguous run in memory (32 bytes per
+// row): a tile's share of a k step is fetched in whole cache lines, one contiguous kilobyte per wave
+// instruction, instead of 32 bytes out of each of 32 lines as a [rows][K] image would give.  A stage of the
+// LDS ring holds the BM + BN rows of all six planes, rows back to back (no padding: lane (r, h) reads the 16
+// bytes at row r, half h, so a wave's fragment read is one contiguous kilobyte, conflict-free).  The stage is
+// filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = 32 rows per instruction, no register and
+// no vector instruction spent), three stages deep.
+template <int BM, int BN>
+struct PlaneStage {
+    static constexpr int KS = 16;
+    static constexpr int STAGES = 3;
+    static constexpr int ROWB = 2 * KS;                         // bytes per row per plane
+    static constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
+    static constexpr int STAGE_BYTES = 3 * (PLANE_A + PLANE_B);
+    static constexpr int PIECES = STAGE_BYTES / 1024;           // wave instructions per stage
+};
+
 // WAVES_M x WAVES_N waves share one BM x BN tile; KG such wave groups split the
 // block's K range between them (each with its own LDS buffers and its own
 // loads) and their accumulators are summed through LDS, in group order, before
@@ -345,11 +368,16 @@ constexpr int gemm_smem_floats()
 {
     constexpr int GT = 64 * WAVES_M * WAVES_N;
     constexpr int KS = (PREC == 3) ? 16 : BK;
-    using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, PREC == 0 ? 1 : PREC, KS>>::type;
-    using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, PREC == 0 ? 1 : PREC, KS>>::type;
+    constexpr int TPL = (PREC == 0 || PREC == 4) ? 1 : PREC;
+    using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, TPL, KS>>::type;
+    using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, TPL, KS>>::type;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
-    constexpr int MAIN = KG * 2 * (TA::SIZE + TB::SIZE), EPI = KG * WAVES_M * WAVES_N * WTM * (WTN + 4);
-    return MAIN > EPI ? MAIN : EPI;
+    constexpr int MAIN = (PREC == 4) ? PlaneStage<BM, BN>::STAGES * PlaneStage<BM, BN>::STAGE_BYTES / 4
+                                     : KG * 2 * (TA::SIZE + TB::SIZE),
+                  EPI = KG * WAVES_M * WAVES_N * WTM * (WTN + 4);
+    // + 4: the tail split's "last arriver" word lives behind the buffers, in the same array (a second __shared__
+    // object beside an array that LDS-DMA fills makes the compiler drain all loads before every LDS read)
+    return (MAIN > EPI ? MAIN : EPI) + 4;
 }
 
 // One block's share of a GEMM launch: block `block_x` of `grid_x`, LDS at `smem` (gemm_smem_floats() floats).
@@ -360,9 +388,10 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
     constexpr int GT = 64 * WAVES_M * WAVES_N;  // threads of one wave group
     constexpr int GW = WAVES_M * WAVES_N;
     // k extent of one pipeline step: the three-plane tiles take 16 so that two blocks still fit a CU's LDS
-    constexpr int KS = (PREC == 3) ? 16 : BK;
-    using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, PREC == 0 ? 1 : PREC, KS>>::type;
-    using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, PREC == 0 ? 1 : PREC, KS>>::type;
+    constexpr int KS = (PREC == 3 || PREC == 4) ? 16 : BK;
+    constexpr int TPL = (PREC == 0 || PREC == 4) ? 1 : PREC;  // planes of the register-staged bf16 tiles
+    using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, TPL, KS>>::type;
+    using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, TPL, KS>>::type;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
@@ -467,7 +496,87 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if constexpr (PREC == 0 && KG > 1) {
+    if constexpr (PREC == 4) {
+        static_assert(KG == 1 && WAVES_M * WAVES_N == 4, "the plane pipeline is written for four waves");
+        using PS = PlaneStage<BM, BN>;
+        constexpr int PPW = PS::PIECES / 4;  // pieces (1 KB wave instructions) per wave and stage
+        static_assert(PPW * 4 == PS::PIECES, "a stage must split evenly over the four waves");
+        char* const lds = reinterpret_cast<char*>(smem);
+        // this wave's pieces: piece q < 3 BM/32 is plane q / (BM/32), row block q % (BM/32) of A; the rest B alike.
+        // Lane l fetches 16 bytes: row (l >> 1) of the block, k half (l & 1).  Rows past the operand's last one are
+        // clamped (their products land in rows / columns the epilogue never stores).
+        const __bf16* src[PPW];
+        int dst[PPW];
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            const int q = wave * PPW + t;
+            const bool isA = q < 3 * (BM / 32);
+            const int qq = isA ? q : q - 3 * (BM / 32);
+            const int rblocks = isA ? BM / 32 : BN / 32;
+            const int pl = qq / rblocks, rb = qq % rblocks;
+            const int row = rb * 32 + (lane >> 1);
+            if (isA) {
+                const int gr = min(m0 + row, Mr - 1);
+                src[t] = reinterpret_cast<const __bf16*>(A) + pl * a.planeA +
+                         ((long long)(k_begin / KS) * a.lda + gr) * KS + (lane & 1) * 8;
+                dst[t] = pl * PS::PLANE_A + rb * 1024;
+            } else {
+                const int gc = min(n0 + row, a.N - 1);
+                src[t] = reinterpret_cast<const __bf16*>(B) + pl * a.planeB +
+                         ((long long)(k_begin / KS) * a.ldb + gc) * KS + (lane & 1) * 8;
+                dst[t] = 3 * PS::PLANE_A + pl * PS::PLANE_B + rb * 1024;
+            }
+        }
+        const long long stepA = (long long)a.lda * KS, stepB = (long long)a.ldb * KS;  // elements per k step
+        auto issue = [&](int kt) {
+            char* stage = lds + (kt % PS::STAGES) * PS::STAGE_BYTES;
+#pragma unroll
+            for (int t = 0; t < PPW; ++t) {
+                const bool isA = wave * PPW + t < 3 * (BM / 32);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src[t] + kt * (isA ? stepA : stepB)),
+                    (__attribute__((address_space(3))) void*)(stage + dst[t]), 16, 0, 0);
+            }
+        };
+        if (nk > 0) issue(0);
+        if (nk > 1) issue(1);
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt was issued two iterations ago; the only younger loads are stage kt + 1's
+            if (kt + 1 < nk)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // every wave's share of stage kt has landed, and every wave has finished reading stage kt - 1, whose
+            // buffer stage kt + 2 now overwrites
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue(kt + 2);
+            const char* stage = lds + (kt % PS::STAGES) * PS::STAGE_BYTES;
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i][pl] = __builtin_bit_cast(
+                        bf16x8, *reinterpret_cast<const u32x4*>(stage + pl * PS::PLANE_A + (wm + 32 * i + r) * PS::ROWB + h * 16));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j][pl] = __builtin_bit_cast(
+                        bf16x8, *reinterpret_cast<const u32x4*>(stage + 3 * PS::PLANE_A + pl * PS::PLANE_B +
+                                                                (wn + 32 * j + r) * PS::ROWB + h * 16));
+            }
+            // products of plane pairs (pa, pb) with pa + pb <= 2, the small ones first
+#pragma unroll
+            for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+                for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // the epilogue reuses the stages
+    } else if constexpr (PREC == 0 && KG > 1) {
         // K-group configurations run batch-sized GEMMs: a block sees only a handful of k steps, each far
         // shorter than a global load's latency, so the next FDEPTH tiles wait in registers (tile t in slot
         // t % FDEPTH, refilled with tile t + FDEPTH as soon as it has been written to LDS): the block pays
@@ -768,7 +877,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         //           at a barrier, and the slabs are read by loads that bypass the L1 as well (sc1).
         // 16-byte stores: register e of a 32x32 accumulator holds row (e&3) + 8(e>>2) + 4h, so registers
         // 4q..4q+3 go out as one store; every store instruction of a wave is one contiguous 1 KB run.
-        __shared__ int s_last;
+        int& s_last = *reinterpret_cast<int*>(smem + gemm_smem_floats<BM, BN, WAVES_M, WAVES_N, KG, AKC, BKC, PREC>() - 4);
         const long long slab_off = ((long long)tail_tile * parts) * (BM * BN);
         const auto slabs = __builtin_amdgcn_make_buffer_rsrc(
             a.tail_ws + (long long)__builtin_amdgcn_readfirstlane((int)(slab_off >> 8)) * 256, 0,
@@ -982,6 +1091,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *dst = accumulate ? (*dst + s) : s;
 }
 
+// The exact three-way bf16 split of TileB::stage, done once for a whole matrix: x = h0 + h1 + h2, each h the
+// top 16 bits of what is left (truncation), 8 significant bits apiece, written in the k-blocked operand layout
+// of the plane GEMM: the operand has R rows and depth K (K a multiple of 16), planes[pl][k / 16][row][k % 16].
+// The operand is src itself (R = rows, K = cols: an activation matrix or a weight used as W^T), or with
+// `transpose` its transpose (R = cols, K = rows: a weight matrix stored (K, N) used as the B operand of X * W).
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long long rows, long long cols,
+                                                           long long ld, int transpose,
+                                                           unsigned short* __restrict__ planes)
+{
+    const long long total = rows * cols;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // output element
+    if (i >= total) return;
+    const long long R = transpose ? cols : rows;
+    const long long kb = i / (R * 16), row = (i / 16) % R, k = kb * 16 + (i & 15);
+    const long long r = transpose ? k : row, c = transpose ? row : k;
+    const float x0 = src[r * ld + c];
+    const unsigned b0 = __float_as_uint(x0) & 0xffff0000u;
+    const float x1 = x0 - __uint_as_float(b0);
+    const unsigned b1 = __float_as_uint(x1) & 0xffff0000u;
+    const float x2 = x1 - __uint_as_float(b1);
+    planes[i] = (unsigned short)(b0 >> 16);
+    planes[total + i] = (unsigned short)(b1 >> 16);
+    planes[2 * total + i] = (unsigned short)(__float_as_uint(x2) >> 16);
+}
+
 enum TileCfg { CFG_128, CFG_64x128, CFG_64, CFG_64_K2, CFG_32_K4, CFG_COUNT };
 
 inline TileCfg pick_cfg(int M, int N, int K, int batch, int epi)
@@ -1023,6 +1157,13 @@ int launch_cfg(const KArgs& k, bool akc, bool bkc, int grid, hipStream_t s)
     return check_launch("gemm_kernel");
 }
 
+// C = A B^T with both operands given as three bf16 planes (GemmDesc::planes).
+int launch_planes(const KArgs& k, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 1, true, true, 4>), dim3(grid), dim3(256), 0, s, k);
+    return check_launch("gemm_kernel(planes)");
+}
+
 // Resident 128x128-tile blocks of the device: two per CU (LDS bound).
 inline int tail_slots()
 {
@@ -1036,6 +1177,15 @@ inline int tail_slots()
 }
 
 }  // namespace
+
+int split_planes(const float* src, long long rows, long long cols, long long ld, bool transpose, void* planes, hipStream_t s)
+{
+    const long long total = rows * cols;
+    if (total <= 0) return GTG_OK;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, rows, cols, ld,
+                       transpose ? 1 : 0, reinterpret_cast<unsigned short*>(planes));
+    return check_launch("split_planes_kernel");
+}
 
 void gemm_tail_workspace(size_t* ws_bytes, size_t* counter_bytes)
 {
@@ -1093,11 +1243,20 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
     }
     if (d.epi == EPI_MASK && !d.aux) return set_error(GTG_ERR_INVALID, "gemm: mask epilogue without aux");
 
-    const TileCfg cfg = pick_cfg(d.M, d.N, d.K, d.batch, d.epi);
+    const TileCfg cfg = d.planes ? CFG_128 : pick_cfg(d.M, d.N, d.K, d.batch, d.epi);
     int bm, bn;
     cfg_dims(cfg, bm, bn);
+    if (d.planes) {
+        if (d.batch != 1 || d.splits > 1 || d.epi == EPI_POOL || d.k_dev != nullptr || d.batch_dim != nullptr ||
+            d.K % 16 != 0 || d.lda < d.M || d.ldb < d.N || d.planeA % 8 != 0 || d.planeB % 8 != 0 ||
+            (reinterpret_cast<uintptr_t>(d.A) & 15) != 0 || (reinterpret_cast<uintptr_t>(d.B) & 15) != 0)
+            return set_error(GTG_ERR_INVALID, "gemm: plane operands need batch 1, no split-K, K a multiple of 16 and "
+                                              "16-byte aligned rows and planes");
+    }
 
     KArgs& k = p.k;
+    k.planeA = d.planeA;
+    k.planeB = d.planeB;
     k.A = d.A;
     k.B = d.B;
     k.C = d.C;
@@ -1197,7 +1356,8 @@ int gemm(const GemmDesc& d, hipStream_t s)
     // a launch whose row count (":m"), depth (":k") or per-graph extent (":g") is read on the device is tagged so:
     // the dimensions recorded with it are then upper bounds, not the work done
     char tag[32];
-    snprintf(tag, sizeof(tag), "%s%s", kNames[(int)cfg][lay], d.m_dev ? ":m" : d.k_dev ? ":k" : d.batch_dim ? ":g" : "");
+    snprintf(tag, sizeof(tag), "%s%s%s", kNames[(int)cfg][lay], d.planes ? "_planes" : "",
+             d.m_dev ? ":m" : d.k_dev ? ":k" : d.batch_dim ? ":g" : "");
     ProfScope prof(s, tag, (long long)d.M * d.batch, d.N, d.K);
     // the matrix pipe applies to the 128x128 configuration (the MFMA-bound GEMMs); the small-tile
     // configurations are latency-bound and stay on the fp32 pipe
@@ -1205,7 +1365,9 @@ int gemm(const GemmDesc& d, hipStream_t s)
     int rc;
     switch (cfg) {
         case CFG_128:
-            if (prec == 3)
+            if (d.planes)
+                rc = launch_planes(k, (int)grid, s);
+            else if (prec == 3)
                 rc = launch_cfg<128, 128, 2, 2, 1, 3>(k, d.a_kc, d.b_kc, (int)grid, s);
             else if (prec == 1)
                 rc = launch_cfg<128, 128, 2, 2, 1, 1>(k, d.a_kc, d.b_kc, (int)grid, s);

@@ -608,6 +608,133 @@ __global__ __launch_bounds__(256) void proto_grad_stage2(const float* __restrict
     dT2c[(int64_t)row_base[0] * d + idx] = s;
 }
 
+// ---- the same gradient rows as three bf16 planes -------------------------------------------------------
+// dT2c is consumed by one GEMM, dZ1c = (dT2c W2) masked by relu.  In the GTG_MATRIX_BF16X3 mode that GEMM takes
+// its operands as exact three-way bf16 splits; written that way here, in the GEMM's k-blocked operand layout
+// planes[pl][c / 16][row][c % 16] (`rows_alloc` rows per k block), the split costs one pass in the producer
+// instead of one per output tile in the consumer.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// x[0..7] -> the eight bf16 of plane 0, 1, 2 (truncation split: each plane the top 16 bits of what is left)
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4_t& p0, u32x4_t& p1, u32x4_t& p2)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a0 = x[2 * q], b0 = x[2 * q + 1];
+        p0[q] = __builtin_amdgcn_perm(__float_as_uint(b0), __float_as_uint(a0), 0x07060302u);
+        const float a1 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u);
+        const float b1 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u);
+        p1[q] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(a1), 0x07060302u);
+        const float a2 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);
+        const float b2 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
+        p2[q] = __builtin_amdgcn_perm(__float_as_uint(b2), __float_as_uint(a2), 0x07060302u);
+    }
+}
+
+constexpr int GP_MAX_D = 1024;
+// blocks [0, pg_blocks): stage 1 of the prototype rows' gradient; block pg_blocks + b: graph b's rows
+// dT2c[off_b + j, c] = adj[b, am, j] * dpool[b, c], j < n_b.  A thread takes (row j, eight columns): 16-byte
+// stores, consecutive threads on consecutive rows of one k block (contiguous in the k-blocked layout).
+__global__ __launch_bounds__(256) void pool_bwd_gather_planes_kernel(
+    const float* __restrict__ adj, const float* __restrict__ dpool, const int32_t* __restrict__ argmax,
+    const int32_t* __restrict__ meta, int B, int n, int d, long long rows_alloc, unsigned short* __restrict__ planes,
+    int32_t* __restrict__ zero, int zero_count, float* __restrict__ pg_partial, int pg_blocks)
+{
+    __shared__ float sadj[64 * 65];
+    __shared__ float gS[GP_MAX_D];
+    __shared__ int amS[GP_MAX_D];
+    if ((int)blockIdx.x < pg_blocks) {
+        const int q = blockIdx.x, ncb = (d + 63) / 64;
+        if (q < ncb * PG_SEG) proto_grad_stage1_block(sadj, q % ncb, q / ncb, dpool, argmax, meta, B, n, d, pg_partial);
+        return;
+    }
+    const int b = blockIdx.x - pg_blocks, tid = threadIdx.x;
+    for (int i = b * 256 + tid; i < zero_count; i += B * 256) zero[i] = 0;   // the following GEMM's arrival counters
+    const int nb = meta[b], off = meta[B + b];
+    const float* src = adj + (int64_t)b * n * n;
+    for (int idx = tid; idx < nb * n; idx += 256) sadj[(idx / n) * 65 + (idx % n)] = src[idx];
+    for (int c = tid; c < d; c += 256) {
+        const int am = argmax[(int64_t)b * d + c];
+        const bool real = am < nb;    // a prototype row that won the maximum has no edge to a stored row
+        gS[c] = real ? dpool[(int64_t)b * d + c] : 0.f;
+        amS[c] = real ? am : 0;
+    }
+    __syncthreads();
+    const int kblocks = d / 16;
+    const long long plane = (long long)kblocks * rows_alloc * 16;
+    const int items = kblocks * nb * 2;
+    for (int idx = tid; idx < items; idx += 256) {
+        const int half = idx & 1, rk = idx >> 1, j = rk % nb, kb = rk / nb;
+        const int c0 = kb * 16 + half * 8;
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = sadj[amS[c0 + u] * 65 + j] * gS[c0 + u];
+        u32x4_t p0, p1, p2;
+        split8(x, p0, p1, p2);
+        unsigned short* dst = planes + ((long long)kb * rows_alloc + off + j) * 16 + half * 8;
+        *reinterpret_cast<u32x4_t*>(dst) = p0;
+        *reinterpret_cast<u32x4_t*>(dst + plane) = p1;
+        *reinterpret_cast<u32x4_t*>(dst + 2 * plane) = p2;
+    }
+}
+
+// stage 2 of the prototype rows' gradient: the ordered sum of the segments, kept as fp32 (proto_rows, (n, d):
+// the sparse dW2 kernel reads it) and written as planes at rows R .. R + n - 1.  A block sums 256 consecutive
+// elements of the (n, d) table (coalesced, the 32 segment loads in flight together), then 32 of its threads
+// split eight each.  Blocks from stage2_blocks on split the weight matrix the same GEMM multiplies by
+// (w: (w_rows, w_cols) fp32, leading dimension w_ld, used transposed: operand rows = w_cols, depth = w_rows),
+// one output element per thread, so that both operands are ready after one launch.
+__global__ __launch_bounds__(256) void proto_grad_stage2_planes(const float* __restrict__ partial,
+                                                                const int32_t* __restrict__ row_base, int n, int d,
+                                                                long long rows_alloc, float* __restrict__ proto_rows,
+                                                                unsigned short* __restrict__ planes, int stage2_blocks,
+                                                                const float* __restrict__ w, int w_rows, int w_cols,
+                                                                int w_ld, unsigned short* __restrict__ w_planes)
+{
+    __shared__ float sm[256];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= stage2_blocks) {
+        const long long total = (long long)w_rows * w_cols;
+        const long long i = (long long)(blockIdx.x - stage2_blocks) * 256 + tid;   // output element
+        if (i >= total) return;
+        const long long kb = i / ((long long)w_cols * 16), row = (i / 16) % w_cols, k = kb * 16 + (i & 15);
+        const float x0 = w[k * w_ld + row];
+        const unsigned b0 = __float_as_uint(x0) & 0xffff0000u;
+        const float x1 = x0 - __uint_as_float(b0);
+        const unsigned b1 = __float_as_uint(x1) & 0xffff0000u;
+        const float x2 = x1 - __uint_as_float(b1);
+        w_planes[i] = (unsigned short)(b0 >> 16);
+        w_planes[total + i] = (unsigned short)(b1 >> 16);
+        w_planes[2 * total + i] = (unsigned short)(__float_as_uint(x2) >> 16);
+        return;
+    }
+    const int total = n * d, idx = blockIdx.x * 256 + tid;
+    float s = 0.f;
+    if (idx < total) {
+        float v[PG_SEG];
+#pragma unroll
+        for (int k = 0; k < PG_SEG; ++k) v[k] = partial[(int64_t)k * total + idx];
+#pragma unroll
+        for (int k = 0; k < PG_SEG; ++k) s += v[k];
+        proto_rows[idx] = s;
+    }
+    sm[tid] = s;
+    __syncthreads();
+    const int e0 = blockIdx.x * 256 + tid * 8;
+    if (tid >= 32 || e0 >= total) return;
+    const int i = e0 / d, c0 = e0 % d;   // d is a multiple of 16: the eight share a row and half a k block
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = sm[tid * 8 + u];
+    u32x4_t p0, p1, p2;
+    split8(x, p0, p1, p2);
+    const long long plane = (long long)(d / 16) * rows_alloc * 16;
+    unsigned short* dst = planes + ((long long)(c0 / 16) * rows_alloc + row_base[0] + i) * 16 + (c0 & 8);
+    *reinterpret_cast<u32x4_t*>(dst) = p0;
+    *reinterpret_cast<u32x4_t*>(dst + plane) = p1;
+    *reinterpret_cast<u32x4_t*>(dst + 2 * plane) = p2;
+}
+
 __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ out,
                                                           const float* __restrict__ dout, int64_t total,
                                                           float* __restrict__ dy)
@@ -976,6 +1103,32 @@ int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t*
     if (int rc = check_launch("pool_bwd_gather_compact_kernel")) return rc;
     hipLaunchKernelGGL(proto_grad_stage2, dim3((n * d + 255) / 256), dim3(256), 0, s, pg_partial, meta + 2 * B, n, d, dT2);
     return check_launch("proto_grad_stage2");
+}
+
+bool pool_bwd_gather_planes_applies(int n, int d) { return n >= 1 && n <= 64 && d % 16 == 0 && d <= GP_MAX_D; }
+
+// dT2c as the plane GEMM's A operand: planes (3, d / 16, rows_alloc, 16) bf16, real rows and prototype rows; the
+// prototype rows also as fp32 (proto_rows, (n, d)).  d a multiple of 16, at most 1024.  The second launch also
+// splits the weight w ((w_rows, w_cols), leading dimension w_ld; w_rows a multiple of 16) into w_planes, laid out
+// as the GEMM's B operand for a product with w: (3, w_rows / 16, w_cols, 16).
+int pool_bwd_gather_planes(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta, int64_t B,
+                           int n, int d, long long rows_alloc, void* planes, float* proto_rows, float* pg_partial,
+                           int32_t* zero, int zero_count, const float* w, int w_rows, int w_cols, int w_ld,
+                           void* w_planes, hipStream_t s)
+{
+    if (!pool_bwd_gather_planes_applies(n, d) || B < 1 || w_rows % 16 != 0 || w_rows < 16 || w_cols < 1 || w_ld < w_cols)
+        return set_error(GTG_ERR_INVALID, "pool_bwd_gather_planes: shape");
+    const int pg_blocks = ((d + 63) / 64) * PG_SEG;
+    hipLaunchKernelGGL(pool_bwd_gather_planes_kernel, dim3((unsigned)(B + pg_blocks)), dim3(256), 0, s, adj, dpool, argmax,
+                       meta, (int)B, n, d, rows_alloc, reinterpret_cast<unsigned short*>(planes), zero, zero_count,
+                       pg_partial, pg_blocks);
+    if (int rc = check_launch("pool_bwd_gather_planes_kernel")) return rc;
+    const int stage2_blocks = (n * d + 255) / 256;
+    const long long w_blocks = ((long long)w_rows * w_cols + 255) / 256;
+    hipLaunchKernelGGL(proto_grad_stage2_planes, dim3((unsigned)(stage2_blocks + w_blocks)), dim3(256), 0, s, pg_partial,
+                       meta + 2 * B, n, d, rows_alloc, proto_rows, reinterpret_cast<unsigned short*>(planes), stage2_blocks, w,
+                       w_rows, w_cols, w_ld, reinterpret_cast<unsigned short*>(w_planes));
+    return check_launch("proto_grad_stage2_planes");
 }
 
 int sigmoid_bwd(const float* out, const float* dout, int64_t total, float* dy, hipStream_t s)

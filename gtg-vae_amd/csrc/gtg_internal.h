@@ -78,6 +78,12 @@ struct GemmDesc {
     // 128x128 configuration only: the epilogue also leaves the column sums of the rows each wave stored, as
     // colsum_part[(tile row * 2 + wave row)][N] (gemm_colsum_rows(M) rows; with m_dev only those of live tiles)
     float* colsum_part = nullptr;
+    // Operands already split into three bf16 planes (the GTG_MATRIX_BF16X3 arithmetic without the split in the
+    // GEMM's loop): A and B then point at k-blocked bf16 images [3][K/16][rows][16] (a_kc = b_kc = true), lda /
+    // ldb are the images' `rows` extents and planeA / planeB plane distances in bf16 elements.  128x128 tiles, batch 1,
+    // K a multiple of 16, no split-K; m_dev, the tail split, every store epilogue and colsum_part apply.
+    bool planes = false;
+    long long planeA = 0, planeB = 0;
 };
 inline int gemm_colsum_rows(int M) { return 2 * ((M + 127) / 128); }
 
@@ -100,6 +106,9 @@ void gemm_tail_workspace(size_t* ws_bytes, size_t* counter_bytes);
 size_t gemm_splitk_workspace(int M, int N, int K, int batch);
 int gemm_pick_splits(int M, int N, int K, int batch);
 int gemm(const GemmDesc& d, hipStream_t s);
+// k-blocked planes [3][K/16][R][16] bf16 of the operand src (R = rows, K = cols) or, with transpose, of its
+// transpose (R = cols, K = rows); src has row pitch ld; K must be a multiple of 16
+int split_planes(const float* src, long long rows, long long cols, long long ld, bool transpose, void* planes, hipStream_t s);
 // Two independent GEMMs; one launch when both run on the 32x32 K-group tile configuration (d0 transposed-A x
 // plain-B, d1 plain-A x plain-B), otherwise one after the other.  Results equal gemm(d0), gemm(d1) bit for bit.
 int gemm_pair(const GemmDesc& d0, const GemmDesc& d1, hipStream_t s);
@@ -143,6 +152,13 @@ int pool_bwd_gather_compact(const float* adj, const float* dpool, const int32_t*
                             int64_t B, int n, int d, float* dT2, float* pg_partial, int32_t* zero, int zero_count,
                             hipStream_t s);
 size_t proto_grad_workspace(int n, int d);
+// the same rows as the plane GEMM's A operand: k-blocked bf16 planes (3, d / 16, rows_alloc, 16), and the prototype
+// rows also as fp32 (proto_rows, (n, d)); d a multiple of 16, at most 1024
+bool pool_bwd_gather_planes_applies(int n, int d);
+int pool_bwd_gather_planes(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta, int64_t B,
+                           int n, int d, long long rows_alloc, void* planes, float* proto_rows, float* pg_partial,
+                           int32_t* zero, int zero_count, const float* w, int w_rows, int w_cols, int w_ld, void* w_planes,
+                           hipStream_t s);
 int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z,
                float* kl_partial, float* kl_out, hipStream_t s);
 // dmu / dlogvar rows have stride ld_out (d, or 2d when they are the two halves of one (B, 2d) matrix)
@@ -180,8 +196,10 @@ int conv1_sparse(const float* adjc, int n, const float* W1, const float* b1, int
 // (gcn_sparse.hip); dT2c supplies only its prototype rows.  partial: dw2_sparse_workspace() bytes.
 bool dw2_sparse_applies(int64_t B, int n, int d, int H);
 size_t dw2_sparse_workspace(int d, int H);
+// proto_rows (nullable): the prototype rows' gradient as an (n, d) block of its own instead of rows R.. of dT2c
 int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, const int32_t* argmax, const int32_t* meta,
-               const float* dT2c, int64_t B, int n, int d, float* partial, float* dW2, hipStream_t s);
+               const float* dT2c, const float* proto_rows, int64_t B, int n, int d, float* partial, float* dW2,
+               hipStream_t s);
 int pool_sparse(const float* adj, const float* t2c, const int32_t* meta, const float* b2, int64_t B, int n, int d,
                 float* pooled, int32_t* argmax, hipStream_t s);
 

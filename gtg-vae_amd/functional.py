@@ -347,6 +347,33 @@ def gemm_rows(A, B, a_kc=True, b_kc=True, rows_dev=None, bias=None, epilogue=0, 
     return C
 
 
+@_on_tensor_device
+def split_planes(x: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """k-blocked bf16 planes (3, K/16, R, 16) of the (R, K) operand x -- or of x^T with transpose -- whose sum is
+    the operand exactly; K must be a multiple of 16."""
+    x = _f32c(x)
+    rows, cols = x.shape
+    R, K = (cols, rows) if transpose else (rows, cols)
+    out = torch.empty((3, K // 16, R, 16), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().gtg_split_planes(ptr(x), rows, cols, x.stride(0), int(transpose), ptr(out), stream_ptr()),
+          "gtg_split_planes")
+    return out
+
+
+@_on_tensor_device
+def gemm_planes_rows(Ap, Bp, rows_dev=None, bias=None, epilogue=0, aux=None, out=None):
+    """Test/profiling hook over gtg_gemm_planes_rows: C = epilogue(A B^T) from k-blocked planes (split_planes)."""
+    L = _lib.lib()
+    _, KB, M, _ = Ap.shape
+    K, N = KB * 16, Bp.shape[2]
+    C = out if out is not None else torch.zeros((M, N), dtype=torch.float32, device=Ap.device)
+    ws = _ws(L.gtg_gemm_rows_workspace_bytes(), Ap.device)
+    check(L.gtg_gemm_planes_rows(ptr(Ap), ptr(Bp), ptr(C), M, N, K, C.stride(0), ptr(_f32c(bias)), epilogue,
+                                 ptr(_f32c(aux)), aux.stride(0) if aux is not None else 0, ptr(rows_dev), ptr(ws),
+                                 ws.numel(), stream_ptr()), "gtg_gemm_planes_rows")
+    return C
+
+
 # ---------------------------------------------------------------------------
 # vocabulary projection + token cross-entropy (text decoder)
 # ---------------------------------------------------------------------------

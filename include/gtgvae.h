@@ -296,6 +296,19 @@ int gtg_gemm_f32_rows(const float* A, const float* B, float* C, int M, int N, in
                       int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, const int32_t* rows_dev,
                       int matrix_mode, void* ws, size_t ws_bytes, void* stream);
 
+/* The three-plane bf16 split GTG_MATRIX_BF16X3 applies to an operand, as a kernel of its own, and the GEMM on
+ * operands that arrive split.  An operand with R rows and depth K (a multiple of 16) is stored k-blocked:
+ * planes (3, K/16, R, 16) bf16, element [p][k/16][r][k%16] = plane p of the value (r, k); the three planes sum
+ * to the fp32 value exactly.  gtg_split_planes splits src (R = rows, K = cols) or, with transpose != 0, its
+ * transpose (R = cols, K = rows).  gtg_gemm_planes_rows: C[:min(M, *rows_dev)] = epilogue(A B^T), A_planes of an
+ * (M, K) operand, B_planes of an (N, K) operand: the six plane products of the BF16X3 mode with no split
+ * arithmetic in the GEMM's loop (the planes reach LDS by global_load_lds, whole cache lines at a time).  What the compact-row encoder's backward runs for
+ * dZ1 = (dT2 W2) masked by relu; exported for tests and profiling.  ws: gtg_gemm_rows_workspace_bytes(). */
+int gtg_split_planes(const float* src, int64_t rows, int64_t cols, int64_t ld, int transpose, void* planes, void* stream);
+int gtg_gemm_planes_rows(const void* A_planes, const void* B_planes, float* C, int M, int N, int K, int ldc,
+                         const float* bias, int epilogue, const float* aux, int ldaux, const int32_t* rows_dev, void* ws,
+                         size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,3 +192,58 @@ def test_bf16x3_pipe_epilogues_ragged_rows_and_split_k():
     g2 = Fn.gemm(X, Y, False, False, matrix_mode="bf16x3")
     assert torch.equal(g1, g2)
     assert (g1.double() - X.double().t() @ Y.double()).abs().max().item() < 2e-3
+
+
+def _unblock(p):
+    """(3, K/16, R, 16) k-blocked planes -> (3, R, K)."""
+    return p.permute(0, 2, 1, 3).reshape(3, p.shape[2], -1)
+
+
+def test_split_planes_sum_is_exact_and_transposes():
+    from gtg_vae_amd import functional as Fn
+
+    torch.manual_seed(5)
+    x = torch.randn(77, 128, device="cuda") * torch.logspace(-6, 6, 128, device="cuda")
+    x[0, :2] = torch.tensor([0.0, -0.0], device="cuda")
+    p = Fn.split_planes(x)
+    assert p.shape == (3, 8, 77, 16) and p.dtype == torch.bfloat16
+    u = _unblock(p).float()
+    assert torch.equal(u[0] + u[1] + u[2], x)
+    assert float((u[1].abs() > u[0].abs() * 2.0 ** -7).sum()) == 0       # each plane carries the next 8 bits
+    xt = x.t().contiguous()                                             # (128, 77): the operand is its transpose
+    pt = Fn.split_planes(xt, transpose=True)
+    assert torch.equal(pt, p)
+    view = torch.randn(40, 100, device="cuda")[:, 3:67]                 # row pitch larger than the width
+    assert torch.equal(_unblock(Fn.split_planes(view)).float().sum(0), view)
+
+
+@pytest.mark.parametrize("M,N,K,rows", [(128, 128, 16, None), (256, 384, 96, None), (300, 200, 48, None),
+                                        (1000, 1024, 512, 777), (20759, 1024, 512, None), (4224, 512, 1024, 4100)])
+@pytest.mark.parametrize("epi", [0, 3])
+def test_gemm_on_presplit_planes_matches_float64_and_the_in_loop_split(M, N, K, rows, epi):
+    """The GEMM on operands that arrive as three bf16 planes (global_load_lds staging, no split arithmetic in
+    the loop): fp32-level error against float64, bit-identical to the GTG_MATRIX_BF16X3 GEMM that splits the
+    same fp32 operands in its loop (same planes, same products, same order), ragged row counts read on the
+    device and the tail split included."""
+    from gtg_vae_amd import functional as Fn
+
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda")
+    aux = torch.randn(M, N, device="cuda") if epi == 3 else None
+    rows_dev = None if rows is None else torch.tensor([rows], dtype=torch.int32, device="cuda")
+    got = Fn.gemm_planes_rows(Fn.split_planes(A), Fn.split_planes(W), rows_dev, epilogue=epi, aux=aux)
+    live = M if rows is None else rows
+    want = A[:live].double() @ W.double().t()
+    if epi == 3:
+        want = torch.where(aux[:live] > 0, want, torch.zeros_like(want))
+    err = (got[:live].double() - want).abs().max().item()
+    assert err <= _tol(K) * max(want.abs().max().item(), 1.0) * 4, err
+    assert float(got[live:].abs().max()) == 0.0 if live < M else True     # rows past the device count are not written
+    if ((M + 127) // 128) * ((N + 127) // 128) >= 192:    # shapes the in-loop split also runs on 128x128 tiles
+        same = Fn.gemm_rows(A, W, True, True, rows_dev, epilogue=epi, aux=aux, matrix_mode="bf16x3")
+        assert torch.equal(got, same)
+    # the transposed-weight image serves X * W with W stored (K, N)
+    Wkn = W.t().contiguous()
+    got2 = Fn.gemm_planes_rows(Fn.split_planes(A), Fn.split_planes(Wkn, transpose=True), rows_dev, epilogue=epi, aux=aux)
+    assert torch.equal(got2, got)
