@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Launch one GEMM shape a few times (for rocprofv3 --pmc passes).
-usage: gemm_one.py {nt|nn|nnmask|tn|rows_nnmask|rows_nt} [reps]
+usage: gemm_one.py {nt|nn|nnmask|tn|rows_nnmask|rows_nt|rows_planes} [reps]
 The rows_* shapes are the compact-row encoder GEMMs: 32832 allocated rows of which the
-device-side count (20759, the mean of the benchmark's batches) are computed."""
+device-side count (20759, the mean of the benchmark's batches) are computed; rows_planes is
+rows_nnmask with both operands arriving as three bf16 planes (the training step's form)."""
 import os
 import sys
 
@@ -32,6 +33,15 @@ ROWS = 20759
 if which.startswith("rows_"):
     M = 32832
     rd = torch.tensor([ROWS], dtype=torch.int32, device="cuda")
+    if which == "rows_planes":
+        A, W = torch.randn(M, D, device="cuda"), torch.randn(H, D, device="cuda")
+        aux, out = torch.randn(M, H, device="cuda"), torch.empty(M, H, device="cuda")
+        Ap, Wp = Fn.split_planes(A), Fn.split_planes(W)
+        for _ in range(reps):
+            Fn.gemm_planes_rows(Ap, Wp, rd, epilogue=3, aux=aux, out=out)
+        torch.cuda.synchronize()
+        print("done", which, out.shape)
+        sys.exit(0)
     if which == "rows_nnmask":
         A, B, akc, bkc, epi = torch.randn(M, D, device="cuda"), torch.randn(D, H, device="cuda"), True, False, 3
         aux = torch.randn(M, H, device="cuda")

@@ -1,15 +1,27 @@
 #!/bin/bash
-# On the GPU box: regenerate the bench lines and the rocprofv3 kernel summary kept under profiles/ (copy them from
-# gpurun_out/refresh/ afterwards).  Each GPU step runs under its own time limit; the script stops at the first failure.
+# On the GPU box: regenerate the bench lines, the rocprofv3 kernel summary and the counter passes kept under
+# profiles/ (copy them from gpurun_out/refresh/ afterwards).  usage: tools/refresh_profiles.sh r02
+# Each GPU step runs under its own time limit; the script stops at the first failure.  Counter passes run alone
+# (one counter group per run, kernel trace only), the profiled program directly after `--`.
 set -e
-cd /root/repo
+tag=${1:-r02}
+repo=$(pwd)
 export TMPDIR=/tmp
-out=gpurun_out/refresh
+out=$repo/gpurun_out/refresh
 mkdir -p $out
-timeout -k 10 400 python bench.py > $out/r01_bench.json 2> $out/bench.err
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python bench.py > $out/r01_bench_under_rocprof.json 2> $out/prof.err
-cp $out/prof/*/*_kernel_stats.csv $out/r01_bench_kernel_stats.csv
-timeout -k 10 300 python bench.py --nodes 32 --batch 256 --latent 256 --hid 512 > $out/r01_bench_configB.json 2>> $out/bench.err
-timeout -k 10 300 python bench.py --nodes 10 --batch 64 --latent 32 --hid 512 > $out/r01_bench_configA.json 2>> $out/bench.err
-timeout -k 10 300 python tools/joint_bench.py > $out/r01_joint_bench.json 2>> $out/bench.err
+cd /tmp
+timeout -k 10 500 python3 $repo/bench.py > $out/${tag}_bench.json 2> $out/bench.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $repo/bench.py --no-extra --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/prof.err
+cp $out/prof/*/*_kernel_stats.csv $out/${tag}_bench_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | cut -d" " -f1)
+  timeout -s KILL 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_gemm_$n -- python3 $repo/tools/gemm_one.py rows_planes 5 > $out/pmc_gemm_$n.log 2>&1
+  python3 $repo/tools/pmc_summary.py $out/pmc_gemm_$n gemm_kernel > $out/${tag}_pmc_${n}_gemm128_planes.txt
+  cp $out/pmc_gemm_$n/*/*counter_collection.csv $out/${tag}_pmc_${n}_gemm128_planes.csv
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_mst_$c -- python3 $repo/tools/mst_bench.py 3 > $out/pmc_mst_$c.log 2>&1
+  python3 $repo/tools/pmc_summary.py $out/pmc_mst_$c mst_kernel > $out/${tag}_pmc_${c}_mst_triu.txt
+  cp $out/pmc_mst_$c/*/*counter_collection.csv $out/${tag}_pmc_${c}_mst_triu.csv
+done
 echo refreshed
