@@ -55,6 +55,10 @@ _SIGS = {
     "gtg_gather_batch": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, _P, c_int64, _P, _P, c_int64, _P, _P, _P]),
     "gtg_proj_ce_fwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "gtg_proj_ce_fwd": (c_int, [_P] * 4 + [c_int64, c_int, c_int, c_int64] + [_P] * 5 + [c_int64, c_int, _P, c_size_t, _P]),
+    "gtg_lstm_fwd_workspace_bytes": (c_size_t, [c_int] * 4),
+    "gtg_lstm_fwd": (c_int, [_P] * 7 + [c_int] * 5 + [_P] * 3 + [c_int, _P, c_size_t, _P]),
+    "gtg_lstm_bwd_workspace_bytes": (c_size_t, [c_int] * 4),
+    "gtg_lstm_bwd": (c_int, [_P] * 11 + [c_int] * 5 + [_P] * 6 + [c_int, _P, c_size_t, _P]),
     "gtg_proj_ce_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "gtg_proj_ce_bwd": (c_int, [_P] * 5 + [c_int64, c_int64, c_int, c_int] + [_P] * 3 + [c_int, _P, c_size_t, _P]),
     "gtg_adam_step": (c_int, [_P] * 4 + [c_int64, _P, c_float, c_float, c_float, c_float, c_float, _P]),

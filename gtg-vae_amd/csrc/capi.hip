@@ -861,6 +861,54 @@ int gtg_gather_batch(const int64_t* edges_local, int64_t total_edges, const int6
 }
 
 // ---------------------------------------------------------------------------
+// one-layer LSTM over a padded sequence
+// ---------------------------------------------------------------------------
+size_t gtg_lstm_fwd_workspace_bytes(int T, int B, int I, int H)
+{
+    return lstm_applies(T, B, I, H) ? lstm_fwd_workspace(T, B, I, H) : 0;
+}
+
+size_t gtg_lstm_bwd_workspace_bytes(int T, int B, int I, int H)
+{
+    return lstm_applies(T, B, I, H) ? lstm_bwd_workspace(T, B, I, H) : 0;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int gtg_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                 const float* h0, const float* c0, int T, int B, int I, int H, int reverse, float* hs, float* cs,
+                 float* gates, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
+    GTG_REQUIRE(T >= 1 && B >= 1 && I >= 1 && H >= 1, "bad size");
+    GTG_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hs && cs && gates, "null pointer");
+    GTG_REQUIRE(aligned16(x) && aligned16(w_ih) && aligned16(w_hh) && aligned16(b_ih) && aligned16(b_hh) && aligned16(h0) &&
+                    aligned16(c0) && aligned16(hs) && aligned16(cs) && aligned16(gates) && aligned16(ws),
+                "every buffer must be 16-byte aligned");
+    return lstm_fwd(x, w_ih, w_hh, b_ih, b_hh, h0, c0, T, B, I, H, reverse != 0, hs, cs, gates, ws, ws_bytes,
+                    (hipStream_t)stream);
+}
+
+int gtg_lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* h0, const float* c0, const float* hs,
+                 const float* cs, const float* gates, const float* d_hs, const float* d_hT, const float* d_cT, int T,
+                 int B, int I, int H, int reverse, float* dx, float* dw_ih, float* dw_hh, float* db, float* dh0,
+                 float* dc0, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    MatrixModeScope matrix_scope(matrix_mode);
+    GTG_REQUIRE(T >= 1 && B >= 1 && I >= 1 && H >= 1, "bad size");
+    GTG_REQUIRE(x && w_ih && w_hh && hs && cs && gates && dw_ih && dw_hh && db, "null pointer");
+    GTG_REQUIRE(aligned16(x) && aligned16(w_ih) && aligned16(w_hh) && aligned16(h0) && aligned16(c0) && aligned16(hs) &&
+                    aligned16(cs) && aligned16(gates) && aligned16(d_hs) && aligned16(d_hT) && aligned16(d_cT) &&
+                    aligned16(dx) && aligned16(dw_ih) && aligned16(dw_hh) && aligned16(db) && aligned16(dh0) &&
+                    aligned16(dc0) && aligned16(ws),
+                "every buffer must be 16-byte aligned");
+    return lstm_bwd(x, w_ih, w_hh, h0, c0, hs, cs, gates, d_hs, d_hT, d_cT, T, B, I, H, reverse != 0, dx, dw_ih, dw_hh, db,
+                    dh0, dc0, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
 // optimiser
 // ---------------------------------------------------------------------------
 int gtg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, void* state16,

@@ -217,6 +217,20 @@ size_t ce_bias_grad_workspace(int V);
 int ce_bias_grad(const float* P, int64_t ldp, int V, const float* g, const int32_t* rowmap, int64_t R, float* partial,
                  float* db, hipStream_t s);
 
+// ---- one-layer LSTM over a padded sequence (lstm.hip) ------------------------
+// x (T, B, I), w_ih (4H, I), w_hh (4H, H), biases (4H), h0 / c0 (B, H) nullable; hs / cs (T, B, H) and gates
+// (T, B, 4H) (the gate activations) are outputs and the backward's saved state.  I % 4 == 0, H % 64 == 0.
+bool lstm_applies(int T, int B, int I, int H);
+size_t lstm_fwd_workspace(int T, int B, int I, int H);
+size_t lstm_bwd_workspace(int T, int B, int I, int H);
+int lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* h0,
+             const float* c0, int T, int B, int I, int H, bool reverse, float* hs, float* cs, float* gates, void* ws,
+             size_t ws_bytes, hipStream_t s);
+int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* h0, const float* c0, const float* hs,
+             const float* cs, const float* gates, const float* d_hs, const float* d_hT, const float* d_cT, int T, int B,
+             int I, int H, bool reverse, float* dx, float* dw_ih, float* dw_hh, float* db, float* dh0, float* dc0, void* ws,
+             size_t ws_bytes, hipStream_t s);
+
 // ---- MST (mst.hip) ----------------------------------------------------------
 int mst_triu(const float* rows, int64_t G, int n, int32_t* edges, int32_t* count, hipStream_t s);
 int mst_full(const float* mats, int64_t G, int n, int32_t* edges, int32_t* count, hipStream_t s);

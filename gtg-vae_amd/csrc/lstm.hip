@@ -1,0 +1,548 @@
+// One-layer LSTM (torch.nn.LSTM semantics: gate order i, f, g, o; c' = f c + i g, h' = o tanh(c')), forward
+// and backward over a whole padded sequence, as the text branch runs it (/root/reference/src/text_vae.py:37-40,
+// 54-66: nn.LSTM(512, 1024, 1), bidirectional for the encoder).
+//
+// Work split:
+//   * everything that is one large product over all T steps goes through gemm(): the input projection
+//     X W_ih^T + (b_ih + b_hh) before the recurrence, and dW_ih, dW_hh, dX after the backward recurrence;
+//   * the recurrence itself is one launch per time step.  Forward: gates = h_{t-1} W_hh^T (a (B x H) x (H x 4H)
+//     product, far too short in M to fill the large-tile GEMM) with the LSTM cell as its epilogue.  Operands
+//     are three bf16 planes in the k-blocked layout [plane][K/16][rows][16] (the exact split x = x0 + x1 + x2,
+//     six products per multiply-add, fp32 accumulate): W_hh is split once per call, and each step's epilogue
+//     writes h_t directly as the planes the next step reads, so no step spends an instruction on splitting.
+//     A 64 x 64 tile per block: 64 batch rows x (16 hidden units x 4 gates) -- the rows of W_hh are permuted
+//     so that the four gates of a unit land in one tile and the cell needs no second pass -- which gives
+//     (H/16) x ceil(B/64) blocks, 256 for H = 1024, B = 256: one per CU.
+//   * backward, per step: a pointwise kernel turns (dh_t, dc_t) into the four gate gradients (fp32 for the
+//     large products afterwards, planes for the recurrence), then dh_{t-1} += dG_t W_hh with K = 4H cut into
+//     slabs so that the launch again has a block per CU; the slabs are summed by the next step's pointwise
+//     kernel.
+#include "gtg_internal.h"
+
+namespace gtg {
+
+namespace {
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LT = 64;                        // tile edge (rows of A, rows of B)
+constexpr int LKS = 16;                       // k extent of a pipeline stage = one k block
+constexpr int LSTAGES = 3;
+constexpr int LROWB = 2 * LKS;                // bytes per row and plane in a stage
+constexpr int LPLANE = LT * LROWB;            // 2 KB
+constexpr int LSTAGE_BYTES = 6 * LPLANE;      // three planes of A, three of B
+constexpr int LPPW = 3;                       // 1-KB pieces per wave and stage (12 pieces, 4 waves)
+constexpr int LDC = LT + 4;                   // row pitch of the accumulator tile staged for the epilogue
+
+struct StepArgs {
+    const __bf16* A;      // [3][K/16][rowsA][16]
+    const __bf16* B;      // [3][K/16][rowsB][16]
+    long long planeA, planeB;
+    int rowsA, rowsB;
+    int M, N;             // live rows of A (batch rows), rows of B (output columns)
+    int kb_per_split;     // k blocks per blockIdx.z (0: the product is skipped, the accumulators stay zero)
+    int H;
+    // forward epilogue
+    float* gates;         // (M, 4H): in: this step's input projection with both biases; out: the gate activations
+    const float* c_prev;  // (M, H) or null (zero state)
+    float* h_out;         // (M, H)
+    float* c_out;         // (M, H)
+    __bf16* h_planes;     // [3][H/16][rows_h][16]: h_t as the next step's A operand
+    long long plane_h;
+    int rows_h;
+    // backward epilogue
+    float* slabs;         // [gridDim.z][M][N]
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// four fp32 -> the four bf16 of plane 0, 1, 2 (truncation split: each plane the top 16 bits of what is left)
+__device__ __forceinline__ void split4(const f32x4 x, u32x2& p0, u32x2& p1, u32x2& p2)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float a0 = x[2 * q], b0 = x[2 * q + 1];
+        p0[q] = __builtin_amdgcn_perm(__float_as_uint(b0), __float_as_uint(a0), 0x07060302u);
+        const float a1 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u);
+        const float b1 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u);
+        p1[q] = __builtin_amdgcn_perm(__float_as_uint(b1), __float_as_uint(a1), 0x07060302u);
+        const float a2 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);
+        const float b2 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
+        p2[q] = __builtin_amdgcn_perm(__float_as_uint(b2), __float_as_uint(a2), 0x07060302u);
+    }
+}
+
+// store x (four consecutive k values k0 .. k0+3 of row `row`) into a k-blocked plane image
+__device__ __forceinline__ void store_planes4(__bf16* img, long long plane, int rows, int row, int k0, const f32x4 x)
+{
+    u32x2 p0, p1, p2;
+    split4(x, p0, p1, p2);
+    __bf16* dst = img + ((long long)(k0 >> 4) * rows + row) * 16 + (k0 & 15);
+    *reinterpret_cast<u32x2*>(dst) = p0;
+    *reinterpret_cast<u32x2*>(dst + plane) = p1;
+    *reinterpret_cast<u32x2*>(dst + 2 * plane) = p2;
+}
+
+// C tile (64 x 64) = A rows [m0, m0+64) x B rows [n0, n0+64) over k blocks [kb0, kb0 + nk): LDS-DMA into a
+// three-stage ring (a wave instruction moves 32 rows x 32 bytes = one contiguous kilobyte), counted waits,
+// one barrier per k step, six MFMAs per wave and k step.  FWD: the LSTM cell as epilogue; else raw slabs.
+template <bool FWD>
+__global__ __launch_bounds__(256) void lstm_step_kernel(const StepArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char lds[LSTAGES * LSTAGE_BYTES];
+    static_assert(LT * LDC * 4 <= LSTAGES * LSTAGE_BYTES, "the epilogue's tile must fit the ring");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int n0 = blockIdx.x * LT, m0 = blockIdx.y * LT;
+    const int nk = a.kb_per_split, kb0 = blockIdx.z * nk;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    // this wave's pieces: piece q < 6 is plane q / 2, row block q % 2 of A; the rest B alike.  Lane l fetches 16
+    // bytes: row (l >> 1) of the block, k half (l & 1).  Rows past the operand's last one are clamped (their
+    // products land in rows / columns the epilogue never stores).
+    const __bf16* src[LPPW];
+    int dst[LPPW];
+#pragma unroll
+    for (int t = 0; t < LPPW; ++t) {
+        const int q = wave * LPPW + t;
+        const bool isA = q < 6;
+        const int qq = isA ? q : q - 6;
+        const int pl = qq >> 1, rb = qq & 1;
+        const int row = rb * 32 + (lane >> 1);
+        if (isA) {
+            const int gr = min(m0 + row, a.M - 1);
+            src[t] = a.A + pl * a.planeA + ((long long)kb0 * a.rowsA + gr) * LKS + (lane & 1) * 8;
+            dst[t] = pl * LPLANE + rb * 1024;
+        } else {
+            const int gc = min(n0 + row, a.N - 1);
+            src[t] = a.B + pl * a.planeB + ((long long)kb0 * a.rowsB + gc) * LKS + (lane & 1) * 8;
+            dst[t] = 3 * LPLANE + pl * LPLANE + rb * 1024;
+        }
+    }
+    const long long stepA = (long long)a.rowsA * LKS, stepB = (long long)a.rowsB * LKS;
+    auto issue = [&](int kt) {
+        char* stage = lds + (kt % LSTAGES) * LSTAGE_BYTES;
+#pragma unroll
+        for (int t = 0; t < LPPW; ++t) {
+            const bool isA = wave * LPPW + t < 6;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kt * (isA ? stepA : stepB)),
+                                             (__attribute__((address_space(3))) void*)(stage + dst[t]), 16, 0, 0);
+        }
+    };
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt was issued two iterations ago; the only younger loads are stage kt + 1's
+        if (kt + 1 < nk)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every wave's share of stage kt has landed, and every wave has finished reading stage kt - 1, whose
+        // buffer stage kt + 2 now overwrites
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        const char* stage = lds + (kt % LSTAGES) * LSTAGE_BYTES;
+        bf16x8 fa[3], fb[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            fa[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(stage + pl * LPLANE + (wm + r) * LROWB + h * 16));
+            fb[pl] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const u32x4*>(stage + 3 * LPLANE + pl * LPLANE + (wn + r) * LROWB + h * 16));
+        }
+        // products of plane pairs (pa, pb) with pa + pb <= 2, the small ones first
+#pragma unroll
+        for (int sum = 2; sum >= 0; --sum)
+#pragma unroll
+            for (int pa = 0; pa <= sum; ++pa) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa], fb[sum - pa], acc, 0, 0, 0);
+    }
+    __syncthreads();  // the epilogue reuses the ring
+
+    // accumulator register e of lane (r, h) is element (row (e & 3) + 8 (e >> 2) + 4 h, column r) of the wave's 32 x 32
+    float* const cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[(wm + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn + r] = acc[e];
+    __syncthreads();
+
+    const int row = tid >> 2, gr = m0 + row;
+    if (gr >= a.M) return;
+    if (FWD) {
+        // tile column g * 16 + u is gate g of hidden unit blockIdx.x * 16 + u; a thread takes four units of a row
+        const int H = a.H, u0 = (tid & 3) * 4, unit0 = blockIdx.x * 16 + u0;
+        float* grow = a.gates + (long long)gr * 4 * H + unit0;
+        f32x4 pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(grow + (long long)g * H);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(cs + row * LDC + g * 16 + u0);
+            pre[g] = x + y;
+        }
+        f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+        if (a.c_prev) cp = *reinterpret_cast<const f32x4*>(a.c_prev + (long long)gr * H + unit0);
+        f32x4 gi, gf, gg, go, c, hh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gi[j] = sigmoidf_(pre[0][j]);
+            gf[j] = sigmoidf_(pre[1][j]);
+            gg[j] = tanhf(pre[2][j]);
+            go[j] = sigmoidf_(pre[3][j]);
+            c[j] = gf[j] * cp[j] + gi[j] * gg[j];
+            hh[j] = go[j] * tanhf(c[j]);
+        }
+        *reinterpret_cast<f32x4*>(grow) = gi;
+        *reinterpret_cast<f32x4*>(grow + (long long)H) = gf;
+        *reinterpret_cast<f32x4*>(grow + 2ll * H) = gg;
+        *reinterpret_cast<f32x4*>(grow + 3ll * H) = go;
+        *reinterpret_cast<f32x4*>(a.c_out + (long long)gr * H + unit0) = c;
+        *reinterpret_cast<f32x4*>(a.h_out + (long long)gr * H + unit0) = hh;
+        store_planes4(a.h_planes, a.plane_h, a.rows_h, gr, unit0, hh);
+    } else {
+        const int c0 = (tid & 3) * 16;
+        float* out = a.slabs + ((long long)blockIdx.z * a.M + gr) * a.N + n0 + c0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (n0 + c0 + 4 * q < a.N) *reinterpret_cast<f32x4*>(out + 4 * q) = *reinterpret_cast<const f32x4*>(cs + row * LDC + c0 + 4 * q);
+    }
+}
+
+// W_hh (4H, H) fp32 -> the two plane images the recurrence multiplies by.
+//   wf (forward):  B operand of h W_hh^T, rows permuted so that a 64-row tile holds the four gates of 16 units:
+//                  [pl][H/16][4H rows p][16], p = (u / 16) * 64 + g * 16 + u % 16  <-  W_hh[g H + u][k]
+//   wb (backward): B operand of dG W_hh (depth = the 4H gate rows in their own order):
+//                  [pl][4H/16][H rows j][16]  <-  W_hh[q][j]
+// One output element per thread; either image may be null.
+__global__ __launch_bounds__(256) void lstm_wsplit_kernel(const float* __restrict__ w, int H, unsigned short* __restrict__ wf,
+                                                          unsigned short* __restrict__ wb)
+{
+    const long long total = 4ll * H * H;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool back = i >= total;
+    if (back) i -= total;
+    if (i >= total) return;
+    unsigned short* dst = back ? wb : wf;
+    if (dst == nullptr) return;
+    float x0;
+    if (!back) {
+        const long long kb = i / (64ll * H), p = (i >> 4) % (4ll * H);
+        const int kk = (int)(i & 15);
+        const long long nb = p >> 6;
+        const int g = (int)(p & 63) >> 4, u = (int)(p & 15);
+        x0 = w[((long long)g * H + nb * 16 + u) * H + kb * 16 + kk];
+    } else {
+        const long long kb = i / (16ll * H), j = (i >> 4) % H;
+        const int kk = (int)(i & 15);
+        x0 = w[(kb * 16 + kk) * H + j];
+    }
+    const unsigned b0 = __float_as_uint(x0) & 0xffff0000u;
+    const float x1 = x0 - __uint_as_float(b0);
+    const unsigned b1 = __float_as_uint(x1) & 0xffff0000u;
+    const float x2 = x1 - __uint_as_float(b1);
+    dst[i] = (unsigned short)(b0 >> 16);
+    dst[total + i] = (unsigned short)(b1 >> 16);
+    dst[2 * total + i] = (unsigned short)(__float_as_uint(x2) >> 16);
+}
+
+// out = a + b (the two bias vectors), and optionally x (rows, cols) -> planes [3][cols/16][rows][16] (an initial
+// hidden state as the first step's A operand); a thread takes four consecutive elements
+__global__ __launch_bounds__(256) void lstm_prepare_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                           float* __restrict__ out, const float* __restrict__ x, int rows,
+                                                           int cols, __bf16* __restrict__ planes, long long plane)
+{
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i < n) {
+        const f32x4 va = *reinterpret_cast<const f32x4*>(a + i), vb = *reinterpret_cast<const f32x4*>(b + i);
+        *reinterpret_cast<f32x4*>(out + i) = va + vb;
+    }
+    if (x != nullptr && i < (long long)rows * cols) {
+        const int row = (int)(i / cols), k0 = (int)(i % cols);
+        store_planes4(planes, plane, rows, row, k0, *reinterpret_cast<const f32x4*>(x + i));
+    }
+}
+
+// The cell's backward at one step, four hidden units of a row per thread.
+//   dh = d_hs (if given) + d_extra (if given) + the Z slabs of dG_{t+1} W_hh (if Z > 0)
+//   dc = dc_io (if !first) + d_cT (if first and given) + dh o (1 - tanh(c)^2)
+// writes the pre-activation gradients dG (M, 4H) fp32 and as planes [3][4H/16][M][16], and dc_io = dc f.
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_t,
+                                                            const float* __restrict__ c_prev, const float* __restrict__ d_hs,
+                                                            const float* __restrict__ d_extra, const float* __restrict__ slabs,
+                                                            int Z, const float* __restrict__ d_cT, int first,
+                                                            float* __restrict__ dc_io, float* __restrict__ dG,
+                                                            __bf16* __restrict__ dG_planes, long long plane, int M, int H)
+{
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long long MH = (long long)M * H;
+    if (i >= MH) return;
+    const int row = (int)(i / H), u0 = (int)(i % H);
+    f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+    if (d_hs) dh += *reinterpret_cast<const f32x4*>(d_hs + i);
+    if (d_extra) dh += *reinterpret_cast<const f32x4*>(d_extra + i);
+    for (int z = 0; z < Z; ++z) dh += *reinterpret_cast<const f32x4*>(slabs + z * MH + i);
+    f32x4 dc = {0.f, 0.f, 0.f, 0.f};
+    if (!first)
+        dc = *reinterpret_cast<const f32x4*>(dc_io + i);
+    else if (d_cT)
+        dc = *reinterpret_cast<const f32x4*>(d_cT + i);
+    const float* grow = gates + (long long)row * 4 * H + u0;
+    const f32x4 gi = *reinterpret_cast<const f32x4*>(grow), gf = *reinterpret_cast<const f32x4*>(grow + (long long)H);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(grow + 2ll * H), go = *reinterpret_cast<const f32x4*>(grow + 3ll * H);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(c_t + i);
+    f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+    if (c_prev) cp = *reinterpret_cast<const f32x4*>(c_prev + i);
+    f32x4 di, df, dg, dO, dcp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float tc = tanhf(c[j]);
+        const float dcj = dc[j] + dh[j] * go[j] * (1.f - tc * tc);
+        dO[j] = dh[j] * tc * go[j] * (1.f - go[j]);
+        di[j] = dcj * gg[j] * gi[j] * (1.f - gi[j]);
+        df[j] = dcj * cp[j] * gf[j] * (1.f - gf[j]);
+        dg[j] = dcj * gi[j] * (1.f - gg[j] * gg[j]);
+        dcp[j] = dcj * gf[j];
+    }
+    *reinterpret_cast<f32x4*>(dc_io + i) = dcp;
+    float* drow = dG + (long long)row * 4 * H + u0;
+    *reinterpret_cast<f32x4*>(drow) = di;
+    *reinterpret_cast<f32x4*>(drow + (long long)H) = df;
+    *reinterpret_cast<f32x4*>(drow + 2ll * H) = dg;
+    *reinterpret_cast<f32x4*>(drow + 3ll * H) = dO;
+    store_planes4(dG_planes, plane, M, row, u0, di);
+    store_planes4(dG_planes, plane, M, row, H + u0, df);
+    store_planes4(dG_planes, plane, M, row, 2 * H + u0, dg);
+    store_planes4(dG_planes, plane, M, row, 3 * H + u0, dO);
+}
+
+// out = the Z slabs summed in order
+__global__ __launch_bounds__(256) void lstm_slab_sum_kernel(const float* __restrict__ slabs, int Z, long long n, float* __restrict__ out)
+{
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < Z; ++z) s += *reinterpret_cast<const f32x4*>(slabs + z * n + i);
+    *reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+struct Carve {
+    char* base;
+    size_t off = 0, cap;
+    Carve(void* b, size_t c) : base(reinterpret_cast<char*>(b)), cap(c) {}
+    template <typename T>
+    T* take(size_t count)
+    {
+        off = (off + 255) / 256 * 256;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+    bool overflow() const { return off > cap; }
+};
+
+inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
+// K slabs of the backward step product: enough (M / 64) x (H / 64) x Z blocks for a block per CU
+inline int bwd_slabs(int B, int H)
+{
+    const long long tiles = (long long)((B + LT - 1) / LT) * ((H + LT - 1) / LT);
+    int z = 1;
+    while (z < 16 && tiles * z < 256 && ((4 * H / 16) % (2 * z)) == 0) z *= 2;
+    return z;
+}
+
+struct FwdWs {
+    float* bias;
+    unsigned short* wf;
+    __bf16* hp[2];
+};
+void fwd_layout(Carve& c, int B, int H, FwdWs* w)
+{
+    w->bias = c.take<float>(4 * (size_t)H);
+    w->wf = c.take<unsigned short>(12 * (size_t)H * H);
+    w->hp[0] = c.take<__bf16>(3 * (size_t)B * H);
+    w->hp[1] = c.take<__bf16>(3 * (size_t)B * H);
+}
+
+struct BwdWs {
+    unsigned short* wb;
+    __bf16* dgp;
+    float *slabs, *dc, *dG, *cs, *gemm_slabs;
+};
+void bwd_layout(Carve& c, int T, int B, int I, int H, BwdWs* w)
+{
+    const size_t TB = (size_t)T * B;
+    w->wb = c.take<unsigned short>(12 * (size_t)H * H);
+    w->dgp = c.take<__bf16>(3 * (size_t)B * 4 * H);
+    w->slabs = c.take<float>((size_t)bwd_slabs(B, H) * B * H);
+    w->dc = c.take<float>((size_t)B * H);
+    w->dG = c.take<float>(TB * 4 * H);
+    w->cs = reinterpret_cast<float*>(c.take<char>(colsum_workspace((int64_t)TB, 4 * H)));
+    w->gemm_slabs = reinterpret_cast<float*>(c.take<char>(
+        max2(gemm_splitk_workspace(4 * H, I, (int)TB, 1), gemm_splitk_workspace(4 * H, H, (int)TB, 1))));
+}
+
+}  // namespace
+
+bool lstm_applies(int T, int B, int I, int H)
+{
+    return T >= 1 && B >= 1 && I >= 4 && I % 4 == 0 && H >= 64 && H % 64 == 0 && (long long)T * B * 4 * H < (1ll << 31);
+}
+
+size_t lstm_fwd_workspace(int T, int B, int I, int H)
+{
+    (void)T; (void)I;
+    Carve c(nullptr, 0);
+    FwdWs w;
+    fwd_layout(c, B, H, &w);
+    return c.off;
+}
+
+size_t lstm_bwd_workspace(int T, int B, int I, int H)
+{
+    Carve c(nullptr, 0);
+    BwdWs w;
+    bwd_layout(c, T, B, I, H, &w);
+    return c.off;
+}
+
+// x (T, B, I); gates (T, B, 4H), hs / cs (T, B, H) are outputs (gates: the activations, kept for the backward).
+// Time runs T-1 .. 0 when `reverse`.  h0 / c0 (B, H) nullable = zero state.
+int lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* h0,
+             const float* c0, int T, int B, int I, int H, bool reverse, float* hs, float* cs, float* gates, void* ws,
+             size_t ws_bytes, hipStream_t s)
+{
+    if (!lstm_applies(T, B, I, H)) return set_error(GTG_ERR_UNSUPPORTED, "lstm: needs I %% 4 == 0 and H %% 64 == 0 (got I=%d H=%d)", I, H);
+    Carve c(ws, ws_bytes);
+    FwdWs w;
+    fwd_layout(c, B, H, &w);
+    if (ws == nullptr || c.overflow()) return set_error(GTG_ERR_WORKSPACE, "lstm_fwd: workspace too small");
+    const long long plane_h = (long long)B * H;
+    {
+        const long long n4 = max2((size_t)4 * H, h0 ? (size_t)B * H : 0) / 4;
+        hipLaunchKernelGGL(lstm_prepare_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b_ih, b_hh, 4 * H, w.bias, h0,
+                           B, H, w.hp[0], plane_h);
+        if (int rc = check_launch("lstm_prepare_kernel")) return rc;
+        const long long total = 4ll * H * H;
+        hipLaunchKernelGGL(lstm_wsplit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_hh, H, w.wf,
+                           (unsigned short*)nullptr);
+        if (int rc = check_launch("lstm_wsplit_kernel")) return rc;
+    }
+    // the input half of the gates for all steps at once
+    GemmDesc g;
+    g.A = x; g.lda = I; g.a_kc = true;
+    g.B = w_ih; g.ldb = I; g.b_kc = true;
+    g.C = gates; g.ldc = 4 * H; g.M = T * B; g.N = 4 * H; g.K = I;
+    g.bias = w.bias;
+    if (int rc = gemm(g, s)) return rc;
+
+    StepArgs a{};
+    a.B = reinterpret_cast<const __bf16*>(w.wf);
+    a.planeB = 4ll * H * H; a.rowsB = 4 * H;
+    a.planeA = plane_h; a.rowsA = B;
+    a.M = B; a.N = 4 * H; a.H = H;
+    a.plane_h = plane_h; a.rows_h = B;
+    const dim3 grid(H / 16, (B + LT - 1) / LT, 1);
+    for (int st = 0; st < T; ++st) {
+        const int t = reverse ? T - 1 - st : st;
+        const int tp = reverse ? t + 1 : t - 1;
+        a.A = w.hp[st & 1];
+        a.h_planes = w.hp[(st + 1) & 1];
+        a.kb_per_split = (st == 0 && h0 == nullptr) ? 0 : H / 16;
+        a.gates = gates + (long long)t * B * 4 * H;
+        a.c_prev = st == 0 ? c0 : cs + (long long)tp * B * H;
+        a.h_out = hs + (long long)t * B * H;
+        a.c_out = cs + (long long)t * B * H;
+        hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(256), 0, s, a);
+    }
+    return check_launch("lstm_step_kernel<fwd>");
+}
+
+// d_hs (T, B, H), d_hT, d_cT (B, H): gradients w.r.t. every step's output, the final hidden and the final cell
+// state (each nullable = zero).  dx (T, B, I), dh0, dc0 nullable = not wanted.  db (4H) is the gradient of
+// both bias vectors.
+int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* h0, const float* c0, const float* hs,
+             const float* cs, const float* gates, const float* d_hs, const float* d_hT, const float* d_cT, int T, int B,
+             int I, int H, bool reverse, float* dx, float* dw_ih, float* dw_hh, float* db, float* dh0, float* dc0, void* ws,
+             size_t ws_bytes, hipStream_t s)
+{
+    if (!lstm_applies(T, B, I, H)) return set_error(GTG_ERR_UNSUPPORTED, "lstm: needs I %% 4 == 0 and H %% 64 == 0 (got I=%d H=%d)", I, H);
+    Carve c(ws, ws_bytes);
+    BwdWs w;
+    bwd_layout(c, T, B, I, H, &w);
+    if (ws == nullptr || c.overflow()) return set_error(GTG_ERR_WORKSPACE, "lstm_bwd: workspace too small");
+    const long long BH = (long long)B * H, total = 4ll * H * H;
+    hipLaunchKernelGGL(lstm_wsplit_kernel, dim3((unsigned)((2 * total + 255) / 256)), dim3(256), 0, s, w_hh, H,
+                       (unsigned short*)nullptr, w.wb);
+    if (int rc = check_launch("lstm_wsplit_kernel")) return rc;
+
+    const int Z = bwd_slabs(B, H);
+    StepArgs a{};
+    a.A = w.dgp; a.planeA = 4ll * BH; a.rowsA = B;
+    a.B = reinterpret_cast<const __bf16*>(w.wb); a.planeB = total; a.rowsB = H;
+    a.M = B; a.N = H; a.H = H;
+    a.kb_per_split = 4 * H / 16 / Z;
+    a.slabs = w.slabs;
+    const dim3 grid((H + LT - 1) / LT, (B + LT - 1) / LT, Z);
+    const unsigned cell_blocks = (unsigned)((BH / 4 + 255) / 256);
+    for (int st = T - 1; st >= 0; --st) {
+        const int t = reverse ? T - 1 - st : st;
+        const int tp = reverse ? t + 1 : t - 1;
+        const bool first = st == T - 1;
+        hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cell_blocks), dim3(256), 0, s, gates + (long long)t * 4 * BH, cs + t * BH,
+                           st == 0 ? c0 : cs + tp * BH, d_hs ? d_hs + t * BH : nullptr, first ? d_hT : nullptr, w.slabs,
+                           first ? 0 : Z, d_cT, first ? 1 : 0, w.dc, w.dG + (long long)t * 4 * BH, w.dgp, 4ll * BH, B, H);
+        if (st > 0 || dh0 != nullptr) hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(256), 0, s, a);
+    }
+    if (int rc = check_launch("lstm backward recurrence")) return rc;
+    if (dh0) {
+        hipLaunchKernelGGL(lstm_slab_sum_kernel, dim3(cell_blocks), dim3(256), 0, s, w.slabs, Z, BH, dh0);
+        if (int rc = check_launch("lstm_slab_sum_kernel")) return rc;
+    }
+    if (dc0 && hipMemcpyAsync(dc0, w.dc, BH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return set_error(GTG_ERR_LAUNCH, "lstm_bwd: copy of dc0 failed");
+
+    const int TB = T * B;
+    if (int rc = colsum(w.dG, TB, 4 * H, 4 * H, w.cs, db, s)) return rc;
+    GemmDesc g;
+    // dW_ih = dG^T X
+    g.A = w.dG; g.lda = 4 * H; g.a_kc = false;
+    g.B = x; g.ldb = I; g.b_kc = false;
+    g.C = dw_ih; g.ldc = I; g.M = 4 * H; g.N = I; g.K = TB;
+    g.splits = gemm_pick_splits(4 * H, I, TB, 1); g.slabs = w.gemm_slabs;
+    if (int rc = gemm(g, s)) return rc;
+    // dW_hh = sum over steps of dG_t^T h_(previous step): a contiguous run of steps in both buffers, plus the
+    // first step against h0
+    if (T > 1) {
+        g = GemmDesc();
+        g.A = w.dG + (reverse ? 0 : 4 * BH); g.lda = 4 * H; g.a_kc = false;
+        g.B = hs + (reverse ? BH : 0); g.ldb = H; g.b_kc = false;
+        g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = (T - 1) * B;
+        g.splits = gemm_pick_splits(4 * H, H, (T - 1) * B, 1); g.slabs = w.gemm_slabs;
+        if (int rc = gemm(g, s)) return rc;
+    } else if (hipMemsetAsync(dw_hh, 0, total * sizeof(float), s) != hipSuccess) {
+        return set_error(GTG_ERR_LAUNCH, "lstm_bwd: clearing dW_hh failed");
+    }
+    if (h0) {
+        g = GemmDesc();
+        g.A = w.dG + (reverse ? (long long)(T - 1) * 4 * BH : 0); g.lda = 4 * H; g.a_kc = false;
+        g.B = h0; g.ldb = H; g.b_kc = false;
+        g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = B;
+        g.epi = EPI_ACCUM;
+        if (int rc = gemm(g, s)) return rc;
+    }
+    if (dx) {
+        g = GemmDesc();
+        g.A = w.dG; g.lda = 4 * H; g.a_kc = true;
+        g.B = w_ih; g.ldb = I; g.b_kc = false;
+        g.C = dx; g.ldc = I; g.M = TB; g.N = I; g.K = 4 * H;
+        if (int rc = gemm(g, s)) return rc;
+    }
+    return GTG_OK;
+}
+
+}  // namespace gtg

@@ -430,6 +430,69 @@ class ProjCEFn(torch.autograd.Function):
         return dH, dW, db, None, None, None
 
 
+def lstm_applies(T: int, B: int, I: int, H: int) -> bool:
+    """Sizes the HIP recurrence takes (include/gtgvae.h, gtg_lstm_fwd)."""
+    return T >= 1 and B >= 1 and I >= 4 and I % 4 == 0 and H >= 64 and H % 64 == 0 and T * B * 4 * H < 2 ** 31
+
+
+class LSTMFn(torch.autograd.Function):
+    """One direction of a one-layer nn.LSTM over a padded sequence (text_vae.py:37-40, called at :57 and :64):
+    x (T, B, I) -> (every step's hidden state (T, B, H) in time order, h_n (B, H), c_n (B, H)).  ``reverse`` runs
+    time backwards (the module's ``*_reverse`` weights); h0 / c0 (B, H) or None."""
+
+    @staticmethod
+    @_on_tensor_device
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, c0, reverse=False, matrix_mode=None):
+        L = _lib.lib()
+        ctx.mode = mode = _lib.matrix_mode(matrix_mode)
+        x, w_ih, w_hh, b_ih, b_hh, h0, c0 = map(_f32c, (x, w_ih, w_hh, b_ih, b_hh, h0, c0))
+        T, B, I = x.shape
+        H = w_hh.shape[1]
+        if w_ih.shape != (4 * H, I) or w_hh.shape != (4 * H, H) or b_ih.numel() != 4 * H or b_hh.numel() != 4 * H or \
+                any(t is not None and t.shape != (B, H) for t in (h0, c0)):
+            raise _lib.GtgError("lstm: x (T, B, I), w_ih (4H, I), w_hh (4H, H), biases (4H), h0 / c0 (B, H)")
+        if not lstm_applies(T, B, I, H):
+            raise _lib.GtgError("lstm: the HIP recurrence needs I % 4 == 0 and H % 64 == 0")
+        dev = x.device
+        hs = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+        cs = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+        gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+        ws = _ws(L.gtg_lstm_fwd_workspace_bytes(T, B, I, H), dev)
+        check(L.gtg_lstm_fwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(h0), ptr(c0), T, B, I, H,
+                             int(bool(reverse)), ptr(hs), ptr(cs), ptr(gates), mode, ptr(ws), ws.numel(), stream_ptr()),
+              "gtg_lstm_fwd")
+        ctx.save_for_backward(x, w_ih, w_hh, h0, c0, hs, cs, gates)
+        ctx.dims = (T, B, I, H, bool(reverse))
+        last = 0 if reverse else T - 1
+        return hs, hs[last].clone(), cs[last].clone()
+
+    @staticmethod
+    @_on_tensor_device
+    def backward(ctx, d_hs, d_hT, d_cT):
+        L = _lib.lib()
+        x, w_ih, w_hh, h0, c0, hs, cs, gates = ctx.saved_tensors
+        T, B, I, H, reverse = ctx.dims
+        d_hs, d_hT, d_cT = map(_f32c, (d_hs, d_hT, d_cT))
+        dev = x.device
+        need = ctx.needs_input_grad
+        dx = torch.empty((T, B, I), dtype=torch.float32, device=dev) if need[0] else None
+        dw_ih = torch.empty((4 * H, I), dtype=torch.float32, device=dev)
+        dw_hh = torch.empty((4 * H, H), dtype=torch.float32, device=dev)
+        db = torch.empty((4 * H,), dtype=torch.float32, device=dev)
+        dh0 = torch.empty((B, H), dtype=torch.float32, device=dev) if (h0 is not None and need[5]) else None
+        dc0 = torch.empty((B, H), dtype=torch.float32, device=dev) if (c0 is not None and need[6]) else None
+        ws = _ws(L.gtg_lstm_bwd_workspace_bytes(T, B, I, H), dev)
+        check(L.gtg_lstm_bwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(h0), ptr(c0), ptr(hs), ptr(cs), ptr(gates), ptr(d_hs),
+                             ptr(d_hT), ptr(d_cT), T, B, I, H, int(reverse), ptr(dx), ptr(dw_ih), ptr(dw_hh), ptr(db),
+                             ptr(dh0), ptr(dc0), ctx.mode, ptr(ws), ws.numel(), stream_ptr()), "gtg_lstm_bwd")
+        return dx, dw_ih, dw_hh, db, db, dh0, dc0, None, None
+
+
+def lstm(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, reverse=False, matrix_mode=None):
+    """(hs (T, B, H), h_n (B, H), c_n (B, H)) of one LSTM direction; see LSTMFn."""
+    return LSTMFn.apply(x, w_ih, w_hh, b_ih, b_hh, h0, c0, reverse, matrix_mode)
+
+
 def proj_ce(H, W, b, targets, padidx, matrix_mode=None):
     """Per-token cross-entropy of the projected decoder outputs and the arg-max token; see ProjCEFn."""
     return ProjCEFn.apply(H, W, b, targets, padidx, matrix_mode)

@@ -2,16 +2,22 @@
 
 Mirrors /root/reference/src/text_vae.py:22-132 (``TextModel``, ``DAE``): same
 sub-module names and shapes, hence the same ``state_dict`` keys
-(``embed, proj, E, G, hgen, z2emb``).  Embeddings and LSTMs run on stock
-PyTorch-ROCm kernels.  The vocabulary projection with its cross-entropy and
-arg-max -- most of the branch's arithmetic, 2*1024*vocab per token -- has a
-HIP path of its own, ``decode_loss``: it skips the pad tokens' rows in all
-three GEMMs and never holds more than one copy of the logits.
+(``embed, proj, E, G, hgen, z2emb``).  Embeddings run on stock PyTorch-ROCm
+kernels.  The LSTMs keep their parameters in ``nn.LSTM`` modules (same
+``state_dict`` keys) but on a GPU, in the default three-plane bf16 matrix
+mode, their forward and backward run through the library's own recurrence
+(``functional.lstm``: one fused product + cell launch per time step); the
+other matrix modes and sizes the recurrence does not take use the stock
+module.  The vocabulary projection with its cross-entropy and arg-max -- most
+of the branch's arithmetic, 2*1024*vocab per token -- has a HIP path of its
+own, ``decode_loss``: it skips the pad tokens' rows in all three GEMMs and
+never holds more than one copy of the logits.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from . import functional as Fn
 from .noise import noisy
 
@@ -42,14 +48,39 @@ class DAE(TextModel):
         self.E.flatten_parameters()
         self.G.flatten_parameters()
 
+    def run_lstm(self, mod, emb, hidden=None, need_output=True):
+        """``mod(emb, hidden)`` for a one-layer ``nn.LSTM``: through functional.lstm, one call per direction, when
+        the input is fp32 on a GPU, the matrix mode is the three-plane bf16 one and the sizes fit; else the stock
+        module.  With ``need_output`` False the (T, B, dirs*H) output is not assembled (None is returned for it)."""
+        T, B, I = emb.shape
+        H = mod.hidden_size
+        mode = _lib.matrix_mode(getattr(self, "matrix_mode", None))
+        if not (emb.is_cuda and emb.dtype == torch.float32 and mode == _lib.MATRIX_MODES["bf16x3"] and
+                mod.num_layers == 1 and Fn.lstm_applies(T, B, I, H)):
+            return mod(emb, hidden)
+        outs, hn, cn = [], [], []
+        for d in range(2 if mod.bidirectional else 1):
+            sfx = "_l0_reverse" if d else "_l0"
+            h0 = hidden[0][d] if hidden is not None else None
+            c0 = hidden[1][d] if hidden is not None else None
+            hs, hT, cT = Fn.lstm(emb, getattr(mod, "weight_ih" + sfx), getattr(mod, "weight_hh" + sfx),
+                                 getattr(mod, "bias_ih" + sfx), getattr(mod, "bias_hh" + sfx), h0, c0, bool(d), mode)
+            outs.append(hs)
+            hn.append(hT)
+            cn.append(cT)
+        output = None
+        if need_output:
+            output = outs[0] if len(outs) == 1 else torch.cat(outs, 2)
+        return output, (torch.stack(hn), torch.stack(cn))
+
     def encode(self, input):
         emb = self.drop(self.embed(input))
-        _, (ht, _) = self.E(emb)
+        _, (ht, _) = self.run_lstm(self.E, emb, need_output=False)
         return self.hgen(torch.cat([ht[-2], ht[-1]], 1))
 
     def decode(self, z, input, hidden=None):
         emb = self.drop(self.embed(input)) + self.z2emb(z)
-        output, hidden = self.G(emb, hidden)
+        output, hidden = self.run_lstm(self.G, emb, hidden)
         output = self.drop(output)
         logits = self.proj(output.view(-1, output.size(-1)))
         return logits.view(output.size(0), output.size(1), -1), hidden
@@ -63,7 +94,7 @@ class DAE(TextModel):
         if matrix_mode is None:
             matrix_mode = getattr(self, "matrix_mode", None)
         emb = self.drop(self.embed(input)) + self.z2emb(z)
-        output, hidden = self.G(emb, hidden)
+        output, hidden = self.run_lstm(self.G, emb, hidden)
         output = self.drop(output)
         loss, pred = Fn.proj_ce(output.reshape(-1, output.size(-1)), self.proj.weight, self.proj.bias,
                                 targets.reshape(-1), self.padidx, matrix_mode)

@@ -266,6 +266,34 @@ int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, c
                     int64_t ldp, int64_t rows, int k, int vocab, float* dH, float* dW, float* db, int matrix_mode,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* ---- one-layer LSTM over a padded sequence (text encoder / decoder) --------
+ * Replaces nn.LSTM(512, 1024, 1) as DAE runs it (src/text_vae.py:37-40: self.E
+ * bidirectional = one call per direction, self.G; called at :57 and :64) and
+ * its backward: gate order i, f, g, o; c' = f c + i g; h' = o tanh(c').
+ *   x (T, B, I), w_ih (4H, I), w_hh (4H, H), b_ih, b_hh (4H), h0, c0 (B, H) or
+ *   NULL (zero state); reverse != 0 runs time T-1 .. 0 (the "_reverse" weights).
+ *   hs (T, B, H): every step's hidden state in time order (the module's
+ *   `output`; its h_n is hs[T-1], or hs[0] when reverse), cs (T, B, H): the cell
+ *   states (c_n likewise), gates (T, B, 4H): the gate activations.  hs, cs and
+ *   gates are the state the backward needs.
+ * Backward takes d_hs (T, B, H), d_hT, d_cT (B, H) -- gradients of the output
+ * sequence, of h_n and of c_n, each may be NULL -- and writes dw_ih (4H, I),
+ * dw_hh (4H, H), db (4H) (the gradient of b_ih and of b_hh alike), and, where
+ * not NULL, dx (T, B, I), dh0, dc0 (B, H).
+ * I must be a multiple of 4 and H of 64 (GTG_ERR_UNSUPPORTED otherwise).  The
+ * recurrent products always run on three bf16 planes per operand with fp32
+ * accumulation (fp32-level error); matrix_mode selects the pipe of the large
+ * products outside the recurrence (input projection, dW, dx). */
+size_t gtg_lstm_fwd_workspace_bytes(int T, int B, int I, int H);
+int gtg_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                 const float* h0, const float* c0, int T, int B, int I, int H, int reverse, float* hs, float* cs,
+                 float* gates, int matrix_mode, void* ws, size_t ws_bytes, void* stream);
+size_t gtg_lstm_bwd_workspace_bytes(int T, int B, int I, int H);
+int gtg_lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* h0, const float* c0, const float* hs,
+                 const float* cs, const float* gates, const float* d_hs, const float* d_hT, const float* d_cT, int T,
+                 int B, int I, int H, int reverse, float* dx, float* dw_ih, float* dw_hh, float* db, float* dh0,
+                 float* dc0, int matrix_mode, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- optimiser -------------------------------------------------------------
  * Replaces optim.Adam(lr, betas=(0.5, 0.999)).step() (src/train.py:290,314)
  * over one flat fp32 buffer.  state16: 16 device bytes, zero-initialised by the

@@ -1,0 +1,115 @@
+"""The HIP LSTM recurrence (gtg_lstm_fwd / gtg_lstm_bwd through functional.lstm) against the CPU oracle's
+explicit cell recurrence (oracle/textvae_oracle.py: lstm, pinned to the reference's own nn.LSTM outputs by
+tests/test_oracle_textvae.py), forward and backward, both directions, with and without an initial state, at
+small ragged sizes and at the text branch's size (text_vae.py:37-40: nn.LSTM(512, 1024), batch 256, 40 steps).
+Tolerances: outputs 1e-5, gradients 1e-4, relative to the largest entry of the tensor compared."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def _params(I, H, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * scale
+    return mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)
+
+
+CASES = [
+    # T, B, I, H, reverse, with initial state
+    (1, 3, 8, 64, False, False),
+    (5, 6, 16, 64, False, True),
+    (5, 6, 16, 64, True, True),
+    (9, 70, 36, 128, True, False),
+    (21, 33, 512, 1024, False, False),
+    (40, 256, 512, 1024, True, False),
+]
+
+
+@pytest.mark.parametrize("T,B,I,H,reverse,init", CASES)
+def test_lstm_forward_and_backward_match_oracle(T, B, I, H, reverse, init):
+    from gtg_vae_amd import functional as Fn
+    from oracle import textvae_oracle as TO
+
+    g = torch.Generator().manual_seed(T * 1000 + B)
+    scale = 1.0 / H ** 0.5
+    w_ih, w_hh, b_ih, b_hh = _params(I, H, 7, scale)
+    x = torch.randn(T, B, I, generator=g)
+    h0 = torch.randn(B, H, generator=g) * 0.5 if init else None
+    c0 = torch.randn(B, H, generator=g) * 0.5 if init else None
+    # upstream gradients of all three results
+    d_hs = torch.randn(T, B, H, generator=g)
+    d_hT = torch.randn(B, H, generator=g)
+    d_cT = torch.randn(B, H, generator=g)
+
+    leaves = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    init_leaves = [t.clone().requires_grad_(True) for t in (h0, c0)] if init else [None, None]
+    out, hT, cT = TO.lstm(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], init_leaves[0], init_leaves[1], reverse)
+    ((out * d_hs).sum() + (hT * d_hT).sum() + (cT * d_cT).sum()).backward()
+
+    cu = [t.clone().cuda().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    cu_init = [t.clone().cuda().requires_grad_(True) for t in (h0, c0)] if init else [None, None]
+    hs, ghT, gcT = Fn.lstm(cu[0], cu[1], cu[2], cu[3], cu[4], cu_init[0], cu_init[1], reverse, "bf16x3")
+    assert _relerr(hs, out) < 1e-5 and _relerr(ghT, hT) < 1e-5 and _relerr(gcT, cT) < 1e-5
+    ((hs * d_hs.cuda()).sum() + (ghT * d_hT.cuda()).sum() + (gcT * d_cT.cuda()).sum()).backward()
+    names = ("x", "w_ih", "w_hh", "b_ih", "b_hh")
+    for name, a, b in zip(names, cu, leaves):
+        assert _relerr(a.grad, b.grad) < 1e-4, (name, _relerr(a.grad, b.grad))
+    if init:
+        for name, a, b in zip(("h0", "c0"), cu_init, init_leaves):
+            assert _relerr(a.grad, b.grad) < 1e-4, (name, _relerr(a.grad, b.grad))
+
+
+def test_lstm_final_state_only_gradient():
+    """The encoder's use (text_vae.py:57-58): only h_n feeds the loss, the output sequence gets no gradient."""
+    from gtg_vae_amd import functional as Fn
+    from oracle import textvae_oracle as TO
+
+    T, B, I, H = 7, 10, 32, 64
+    g = torch.Generator().manual_seed(3)
+    w_ih, w_hh, b_ih, b_hh = _params(I, H, 11, 0.2)
+    x = torch.randn(T, B, I, generator=g)
+    d_hT = torch.randn(B, H, generator=g)
+    for reverse in (False, True):
+        leaves = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+        _, hT, _ = TO.lstm(*leaves, reverse=reverse)
+        (hT * d_hT).sum().backward()
+        cu = [t.clone().cuda().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+        _, ghT, _ = Fn.lstm(*cu, reverse=reverse)
+        (ghT * d_hT.cuda()).sum().backward()
+        assert _relerr(ghT, hT) < 1e-5
+        for a, b in zip(cu, leaves):
+            assert _relerr(a.grad, b.grad) < 1e-4
+
+
+def test_module_routes_through_the_hip_recurrence_and_matches_stock_lstm():
+    """DAE.run_lstm: same results as the stock nn.LSTM module it wraps (both directions, given hidden state),
+    and the stock module is what runs in the fp32 matrix mode."""
+    from gtg_vae_amd.text_vae import DAE
+
+    torch.manual_seed(0)
+    m = DAE(32, 50, 0).cuda().train()
+    emb = torch.randn(6, 5, 512, device="cuda")
+    hidden = (torch.randn(1, 5, 1024, device="cuda") * 0.3, torch.randn(1, 5, 1024, device="cuda") * 0.3)
+    for mod, hid in ((m.E, None), (m.G, None), (m.G, hidden)):
+        want_out, (want_h, want_c) = mod(emb, hid)
+        out, (h, c) = m.run_lstm(mod, emb, hid)
+        assert out.shape == want_out.shape and h.shape == want_h.shape and c.shape == want_c.shape
+        assert _relerr(out, want_out) < 1e-5 and _relerr(h, want_h) < 1e-5 and _relerr(c, want_c) < 1e-5
+    m.matrix_mode = "f32"
+    out, _ = m.run_lstm(m.G, emb, None)
+    assert torch.equal(out, m.G(emb)[0])
+
+
+def test_lstm_rejects_sizes_it_does_not_take():
+    from gtg_vae_amd import _lib
+    from gtg_vae_amd import functional as Fn
+
+    w_ih, w_hh, b_ih, b_hh = (t.cuda() for t in _params(8, 48, 1, 0.1))
+    with pytest.raises(_lib.GtgError):
+        Fn.lstm(torch.randn(3, 2, 8, device="cuda"), w_ih, w_hh, b_ih, b_hh)
