@@ -12,7 +12,7 @@
 //     writes h_t directly as the planes the next step reads, so no step spends an instruction on splitting.
 //     A 64 x 64 tile per block: 64 batch rows x (16 hidden units x 4 gates) -- the rows of W_hh are permuted
 //     so that the four gates of a unit land in one tile and the cell needs no second pass -- which gives
-//     (H/16) x ceil(B/64) blocks, 256 for H = 1024, B = 256: one per CU.
+//     (H/16) x ceil(B/64) blocks, 256 for H = 1024, B = 256: one per CU; the block's four waves split K.
 //   * backward, per step: a pointwise kernel turns (dh_t, dc_t) into the four gate gradients (fp32 for the
 //     large products afterwards, planes for the recurrence), then dh_{t-1} += dG_t W_hh with K = 4H cut into
 //     slabs so that the launch again has a block per CU; the slabs are summed by the next step's pointwise
@@ -30,12 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LT = 64;                        // tile edge (rows of A, rows of B)
-constexpr int LKS = 16;                       // k extent of a pipeline stage = one k block
-constexpr int LSTAGES = 3;
-constexpr int LROWB = 2 * LKS;                // bytes per row and plane in a stage
-constexpr int LPLANE = LT * LROWB;            // 2 KB
-constexpr int LSTAGE_BYTES = 6 * LPLANE;      // three planes of A, three of B
-constexpr int LPPW = 3;                       // 1-KB pieces per wave and stage (12 pieces, 4 waves)
+constexpr int LKS = 16;                       // k extent of one k block of the plane layout
 constexpr int LDC = LT + 4;                   // row pitch of the accumulator tile staged for the epilogue
 
 struct StepArgs {
@@ -87,105 +82,141 @@ __device__ __forceinline__ void store_planes4(__bf16* img, long long plane, int 
     *reinterpret_cast<u32x2*>(dst + 2 * plane) = p2;
 }
 
-// C tile (64 x 64) = A rows [m0, m0+64) x B rows [n0, n0+64) over k blocks [kb0, kb0 + nk): LDS-DMA into a
-// three-stage ring (a wave instruction moves 32 rows x 32 bytes = one contiguous kilobyte), counted waits,
-// one barrier per k step, six MFMAs per wave and k step.  FWD: the LSTM cell as epilogue; else raw slabs.
+// C tile (64 x 64) = A rows [m0, m0+64) x B rows [n0, n0+64) over k blocks [kb0, kb0 + nk).
+//
+// A block is alone on its CU (a block per CU fills the chip) with one wave per SIMD, so nothing but the wave
+// itself can hide its latencies.  Hence: the four waves split K, not the tile.  Wave w multiplies the whole
+// 64 x 64 tile (four 32 x 32 accumulators) over k blocks w, w + 4, ...  Nothing is shared between waves until
+// the end, so the operands skip LDS: in the k-blocked plane layout the 16 bytes lane (r, h) feeds to an MFMA
+// (row r, k half h) of 32 consecutive rows are one contiguous kilobyte, i.e. an MFMA operand is ONE coalesced
+// 16-byte-per-lane load straight into registers.  Four register sets of fragments rotate: three k blocks
+// (36 KB per wave) are in flight while the 24 MFMAs of the fourth run, consecutive MFMAs go to different
+// accumulators, and the loop holds no barrier and no LDS access.  The four partial tiles are summed through
+// LDS by the epilogue.  FWD: the LSTM cell as epilogue; else raw slabs.
+struct Frags {
+    bf16x8 a[2][3], b[2][3];  // [32-row block][plane]
+};
+
 template <bool FWD>
-__global__ __launch_bounds__(256) void lstm_step_kernel(const StepArgs a)
+__global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
 {
-    __shared__ __attribute__((aligned(16))) char lds[LSTAGES * LSTAGE_BYTES];
-    static_assert(LT * LDC * 4 <= LSTAGES * LSTAGE_BYTES, "the epilogue's tile must fit the ring");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int WAVE_LDS = LT * LDC * 4;  // a wave's partial tile
+    __shared__ __attribute__((aligned(16))) char lds[4 * WAVE_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the pipeline's branches are per wave
     const int r = lane & 31, h = lane >> 5;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int n0 = blockIdx.x * LT, m0 = blockIdx.y * LT;
     const int nk = a.kb_per_split, kb0 = blockIdx.z * nk;
+    const int row = tid >> 2, gr = m0 + row;  // the epilogue's row of this thread
 
-    f32x16 acc;
+    // FWD: the cell's inputs are fetched now and used after the product
+    f32x4 pre[4], cp = {0.f, 0.f, 0.f, 0.f};
+    const int u0 = (tid & 3) * 4, unit0 = blockIdx.x * 16 + u0;
+    float* const grow = FWD ? a.gates + (long long)min(gr, a.M - 1) * 4 * a.H + unit0 : nullptr;
+    if (FWD) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-
-    // this wave's pieces: piece q < 6 is plane q / 2, row block q % 2 of A; the rest B alike.  Lane l fetches 16
-    // bytes: row (l >> 1) of the block, k half (l & 1).  Rows past the operand's last one are clamped (their
-    // products land in rows / columns the epilogue never stores).
-    const __bf16* src[LPPW];
-    int dst[LPPW];
-#pragma unroll
-    for (int t = 0; t < LPPW; ++t) {
-        const int q = wave * LPPW + t;
-        const bool isA = q < 6;
-        const int qq = isA ? q : q - 6;
-        const int pl = qq >> 1, rb = qq & 1;
-        const int row = rb * 32 + (lane >> 1);
-        if (isA) {
-            const int gr = min(m0 + row, a.M - 1);
-            src[t] = a.A + pl * a.planeA + ((long long)kb0 * a.rowsA + gr) * LKS + (lane & 1) * 8;
-            dst[t] = pl * LPLANE + rb * 1024;
-        } else {
-            const int gc = min(n0 + row, a.N - 1);
-            src[t] = a.B + pl * a.planeB + ((long long)kb0 * a.rowsB + gc) * LKS + (lane & 1) * 8;
-            dst[t] = 3 * LPLANE + pl * LPLANE + rb * 1024;
-        }
+        for (int g = 0; g < 4; ++g) pre[g] = *reinterpret_cast<const f32x4*>(grow + (long long)g * a.H);
+        // unconditional (a null c_prev reads a dummy that the epilogue discards): a branch here would make the
+        // wave wait for the load before it starts its pipeline
+        const float* cpp = a.c_prev ? a.c_prev + (long long)min(gr, a.M - 1) * a.H + unit0 : grow;
+        asm volatile("" : "+v"(cpp));  // keeps the load unconditional
+        cp = *reinterpret_cast<const f32x4*>(cpp);
     }
-    const long long stepA = (long long)a.rowsA * LKS, stepB = (long long)a.rowsB * LKS;
-    auto issue = [&](int kt) {
-        char* stage = lds + (kt % LSTAGES) * LSTAGE_BYTES;
+
+    f32x16 acc[2][2];
 #pragma unroll
-        for (int t = 0; t < LPPW; ++t) {
-            const bool isA = wave * LPPW + t < 6;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + kt * (isA ? stepA : stepB)),
-                                             (__attribute__((address_space(3))) void*)(stage + dst[t]), 16, 0, 0);
-        }
-    };
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt was issued two iterations ago; the only younger loads are stage kt + 1's
-        if (kt + 1 < nk)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPPW) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // every wave's share of stage kt has landed, and every wave has finished reading stage kt - 1, whose
-        // buffer stage kt + 2 now overwrites
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt + 2);
-        const char* stage = lds + (kt % LSTAGES) * LSTAGE_BYTES;
-        bf16x8 fa[3], fb[3];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            fa[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(stage + pl * LPLANE + (wm + r) * LROWB + h * 16));
-            fb[pl] = __builtin_bit_cast(
-                bf16x8, *reinterpret_cast<const u32x4*>(stage + 3 * LPLANE + pl * LPLANE + (wn + r) * LROWB + h * 16));
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int mine = nk > wave ? (nk - wave + 3) / 4 : 0;  // k blocks of this wave
+    if (mine > 0) {
+        // Rows past the operand's last one are clamped (their products land in rows / columns the epilogue never
+        // stores), k blocks past the wave's last one likewise (fetched again, never multiplied).
+        const __bf16 *pA[2], *pB[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            pA[i] = a.A + ((long long)(kb0 + wave) * a.rowsA + min(m0 + 32 * i + r, a.M - 1)) * LKS + h * 8;
+            pB[i] = a.B + ((long long)(kb0 + wave) * a.rowsB + min(n0 + 32 * i + r, a.N - 1)) * LKS + h * 8;
         }
+        const long long stepA = 4ll * a.rowsA * LKS, stepB = 4ll * a.rowsB * LKS;  // to this wave's next k block
+        auto load = [&](int j, Frags& f) {
+            const int jj = min(j, mine - 1);
+#ifndef GTG_LSTM_ABL_NOLOAD
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f.a[i][pl] = *reinterpret_cast<const bf16x8*>(pA[i] + pl * a.planeA + jj * stepA);
+                    f.b[i][pl] = *reinterpret_cast<const bf16x8*>(pB[i] + pl * a.planeB + jj * stepB);
+                }
+#else
+            (void)jj;
+#endif
+        };
         // products of plane pairs (pa, pb) with pa + pb <= 2, the small ones first
+        auto mma = [&](const Frags& f) {
 #pragma unroll
-        for (int sum = 2; sum >= 0; --sum)
+            for (int sum = 2; sum >= 0; --sum)
 #pragma unroll
-            for (int pa = 0; pa <= sum; ++pa) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa], fb[sum - pa], acc, 0, 0, 0);
+                for (int pa = 0; pa <= sum; ++pa)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn) {
+#ifdef GTG_LSTM_ABL_NOMFMA
+                            acc[i][jn][0] += (float)f.a[i][pa][0] * (float)f.b[jn][sum - pa][0];
+#else
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[jn][sum - pa], acc[i][jn], 0, 0, 0);
+#endif
+                        }
+        };
+        Frags f0{}, f1{}, f2{}, f3{};
+        load(0, f0);
+        load(1, f1);
+        load(2, f2);
+        int j = 0;
+        for (; j + 3 < mine; j += 4) {
+            load(j + 3, f3);
+            mma(f0);
+            load(j + 4, f0);
+            mma(f1);
+            load(j + 5, f1);
+            mma(f2);
+            load(j + 6, f2);
+            mma(f3);
+        }
+        // at most three blocks are left, and they are the ones f0, f1, f2 hold
+        if (j < mine) mma(f0);
+        if (j + 1 < mine) mma(f1);
+        if (j + 2 < mine) mma(f2);
     }
-    __syncthreads();  // the epilogue reuses the ring
 
-    // accumulator register e of lane (r, h) is element (row (e & 3) + 8 (e >> 2) + 4 h, column r) of the wave's 32 x 32
-    float* const cs = reinterpret_cast<float*>(lds);
+    // each wave leaves its partial tile in LDS (accumulator register e of lane (r, h) is element (row
+    // (e & 3) + 8 (e >> 2) + 4 h, column r) of a 32 x 32 block); the four are summed in wave order
+    float* const part = reinterpret_cast<float*>(lds + wave * WAVE_LDS);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) cs[(wm + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn + r] = acc[e];
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + 32 * jn + r] = acc[i][jn][e];
     __syncthreads();
-
-    const int row = tid >> 2, gr = m0 + row;
     if (gr >= a.M) return;
+    auto tile4 = [&](int col) {  // four consecutive columns of this thread's row, summed over the waves
+        f32x4 v = *reinterpret_cast<const f32x4*>(lds + (row * LDC + col) * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(lds + w * WAVE_LDS + (row * LDC + col) * 4);
+        return v;
+    };
     if (FWD) {
         // tile column g * 16 + u is gate g of hidden unit blockIdx.x * 16 + u; a thread takes four units of a row
-        const int H = a.H, u0 = (tid & 3) * 4, unit0 = blockIdx.x * 16 + u0;
-        float* grow = a.gates + (long long)gr * 4 * H + unit0;
-        f32x4 pre[4];
+        const int H = a.H;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(grow + (long long)g * H);
-            const f32x4 y = *reinterpret_cast<const f32x4*>(cs + row * LDC + g * 16 + u0);
-            pre[g] = x + y;
-        }
-        f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-        if (a.c_prev) cp = *reinterpret_cast<const f32x4*>(a.c_prev + (long long)gr * H + unit0);
+        for (int g = 0; g < 4; ++g) pre[g] += tile4(g * 16 + u0);
+        if (a.c_prev == nullptr) cp = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 gi, gf, gg, go, c, hh;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -208,7 +239,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const StepArgs a)
         float* out = a.slabs + ((long long)blockIdx.z * a.M + gr) * a.N + n0 + c0;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (n0 + c0 + 4 * q < a.N) *reinterpret_cast<f32x4*>(out + 4 * q) = *reinterpret_cast<const f32x4*>(cs + row * LDC + c0 + 4 * q);
+            if (n0 + c0 + 4 * q < a.N) *reinterpret_cast<f32x4*>(out + 4 * q) = tile4(c0 + 4 * q);
     }
 }
 
