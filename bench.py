@@ -173,7 +173,7 @@ def joint_bench(dev, steps=8):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"workload": "configs[4] on one GPU: joint graph+text step, batch 256, N=32, d=256, T<=40, vocab 30522; "
-                        "HIP graph half + HIP vocabulary projection/cross-entropy + flat fused Adam, stock LSTMs",
+                        "HIP graph half + HIP LSTM recurrences + HIP vocabulary projection/cross-entropy + flat fused Adam",
             "ms_per_step": dt * 1e3, "graphs_per_s": B / dt, "parameters": tr.numel}
 
 

@@ -24,4 +24,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 $repo/tools/pmc_summary.py $out/pmc_mst_$c mst_kernel > $out/${tag}_pmc_${c}_mst_triu.txt
   cp $out/pmc_mst_$c/*/*counter_collection.csv $out/${tag}_pmc_${c}_mst_triu.csv
 done
+timeout -k 10 300 python3 $repo/tools/joint_bench.py > $out/${tag}_joint_bench.json 2>> $out/bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/jprof -- python3 $repo/tools/joint_bench.py 5 trainer > $out/jprof.log 2>&1
+cp $out/jprof/*/*_kernel_stats.csv $out/${tag}_joint_kernel_stats.csv
+timeout -k 10 200 python3 $repo/tools/lstm_bench.py > $out/${tag}_lstm_bench.txt 2>> $out/bench.err
+timeout -k 10 200 python3 $repo/tools/planes_bench.py > $out/${tag}_planes_bench.txt 2>> $out/bench.err
+timeout -k 10 200 python3 $repo/tools/proj_ce_bench.py > $out/${tag}_proj_ce_bench.json 2>> $out/bench.err
 echo refreshed
