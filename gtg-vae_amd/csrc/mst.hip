@@ -198,7 +198,10 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
                 if ((c & 15) == 15) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        const float diag = TRIU ? T[jc * n - (jc * (jc - 1)) / 2] : T[jc * (MAXN + 1) + jc];
+        // the triangular form goes through U + U^T - diag(U) in the reference (graph_vae.py:67-69): the diagonal is
+        // (d + d) - d, which is d except that +inf gives NaN (vertex absent) and a d above FLT_MAX / 2 gives +inf
+        const float draw = TRIU ? T[jc * n - (jc * (jc - 1)) / 2] : T[jc * (MAXN + 1) + jc];
+        const float diag = TRIU ? (draw + draw) - draw : draw;
         // every LDS read above has returned (waited for just below): the
         // region may be overwritten by the next graph's row now
         if (TRIU) {

@@ -142,6 +142,31 @@ def main():
             out[f"F__{nm}"] = full.numpy()
             out[f"E__{nm}"] = np.asarray(edges, dtype=np.int32).reshape(-1, 2)
             tri_names.append(nm)
+    # the same path with diagonal entries that the expansion U + U^T - diag(U) (graph_vae.py:67-69) does not
+    # return unchanged: +inf becomes inf + inf - inf = NaN (vertex absent), a value above FLT_MAX / 2 becomes
+    # inf - d = inf (present), NaN stays NaN; plus infinite and NaN weights off the diagonal.  A generator of
+    # its own, so that the cases above keep their values.
+    rng2 = np.random.default_rng(20261111)
+    for n in (3, 10, 64):
+        model = gv.GraphVAE(n, 8, 16, n, 1)
+        M = n * (n + 1) // 2
+        diag_pos = np.array([i * n - (i * (i - 1)) // 2 for i in range(n)])
+        for rep, special in enumerate(([np.inf], [3.0e38], [np.inf, 3.0e38, np.nan, -np.inf, 0.5, 0.75])):
+            row = rng2.uniform(0, 1, size=(1, M)).astype(np.float32)
+            hit = rng2.choice(n, size=max(1, n // 3), replace=False)
+            row[0, diag_pos[hit]] = rng2.choice(np.array(special, dtype=np.float32), size=len(hit))
+            if rep == 2:
+                off = np.setdiff1d(np.arange(M), diag_pos)
+                pick = rng2.choice(off, size=max(1, M // 10), replace=False)
+                row[0, pick] = rng2.choice(np.array([np.inf, -np.inf, np.nan, 0.0], dtype=np.float32), size=len(pick))
+            row = torch.from_numpy(row)
+            full = model.recover_full_adj_from_lower(model.recover_adj_lower(row))
+            edges = mst.mst_graph(full)
+            nm = f"triu_diag_n{n}_{rep}"
+            out[f"R__{nm}"] = row.numpy()[0]
+            out[f"F__{nm}"] = full.numpy()
+            out[f"E__{nm}"] = np.asarray(edges, dtype=np.int32).reshape(-1, 2)
+            tri_names.append(nm)
     out["names"] = np.array(names)
     out["triu_names"] = np.array(tri_names)
     np.savez_compressed(os.path.join(HERE, "mst_golden.npz"), **out)

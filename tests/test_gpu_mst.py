@@ -61,6 +61,14 @@ def test_random_batches_match_c_oracle(n):
     iu = np.triu_indices(n)
     diag_pos = np.nonzero(iu[0] == iu[1])[0]
     rows[:, diag_pos] = rng.uniform(0.3, 1.0, size=(G, n)).astype(np.float32)
+    # diagonal entries that the reference's U + U^T - diag(U) does not return unchanged (+inf -> NaN = absent,
+    # above FLT_MAX / 2 -> +inf = present), and non-finite weights
+    special = rng.uniform(size=(G, n)) < 0.1
+    rows[:, diag_pos] = np.where(special, rng.choice(np.array([np.inf, 3e38, np.nan, -np.inf], dtype=np.float32), size=(G, n)),
+                                 rows[:, diag_pos])
+    off = rng.uniform(size=rows.shape) < 0.02
+    off[:, diag_pos] = False
+    rows[off] = rng.choice(np.array([np.inf, -np.inf, np.nan], dtype=np.float32), size=int(off.sum()))
     we, wc = c_mst.mst_triu(rows, n)
     e, c = mst_graph_batched(torch.from_numpy(rows).cuda(), n)
     assert np.array_equal(c.cpu().numpy(), wc)
