@@ -144,7 +144,6 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
         const long long stepA = 4ll * a.rowsA * LKS, stepB = 4ll * a.rowsB * LKS;  // to this wave's next k block
         auto load = [&](int j, Frags& f) {
             const int jj = min(j, mine - 1);
-#ifndef GTG_LSTM_ABL_NOLOAD
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -152,9 +151,6 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
                     f.a[i][pl] = *reinterpret_cast<const bf16x8*>(pA[i] + pl * a.planeA + jj * stepA);
                     f.b[i][pl] = *reinterpret_cast<const bf16x8*>(pB[i] + pl * a.planeB + jj * stepB);
                 }
-#else
-            (void)jj;
-#endif
         };
         // products of plane pairs (pa, pb) with pa + pb <= 2, the small ones first
         auto mma = [&](const Frags& f) {
@@ -165,13 +161,8 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int jn = 0; jn < 2; ++jn) {
-#ifdef GTG_LSTM_ABL_NOMFMA
-                            acc[i][jn][0] += (float)f.a[i][pa][0] * (float)f.b[jn][sum - pa][0];
-#else
+                        for (int jn = 0; jn < 2; ++jn)
                             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[jn][sum - pa], acc[i][jn], 0, 0, 0);
-#endif
-                        }
         };
         Frags f0{}, f1{}, f2{}, f3{};
         load(0, f0);
