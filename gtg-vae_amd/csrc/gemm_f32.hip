@@ -183,28 +183,38 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //               8 significant bits each (fp32 has 24), so that the six products
 //               h_i*h_j, i + j <= 2, summed in fp32 reproduce the fp32 product
 //               to ~2^-22 relative.
-// LDS image per plane: [ROWS][BK bf16 + 16 B pad] = 80 bytes a row, K contiguous
-// for both operand layouts, so a fragment (row, 8 consecutive k) is one
-// conflict-free ds_read_b128.  Every thread owns NP pieces of (row, 8 k): two
-// 16-byte loads when K is contiguous in memory, eight dword loads (coalesced
-// across the 64 rows of a wave) when the rows are.
+// Either way a lane's MFMA fragment is (row r, 8 consecutive k).
+//   KC  (K contiguous in memory): every thread owns pieces of (row, 8 k), two 16-byte loads each; LDS image
+//        per plane [ROWS][TK bf16 + 16 B pad], a fragment is one conflict-free ds_read_b128.
+//   !KC (rows contiguous in memory): every thread owns pieces of (k, 4 rows), one 16-byte load each (a wave
+//        instruction covers two k values x 128 rows, 512 contiguous bytes apiece); the LDS image keeps that
+//        orientation, [TK][ROWS bf16 + 64 B pad], so staging is one 8-byte store per piece and plane, and the
+//        transposition happens in the read: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a
+//        4 (k) x 16 (rows) block, i.e. four consecutive k of one row; two of them make the fragment.  The 64-byte
+//        pad puts the four k rows of a block in disjoint bank windows (conflict-free per 32-lane half).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 template <int ROWS, bool KC, int NTHREADS, int PLANES, int TK>
 struct TileB {
-    static constexpr int ROWB = 2 * TK + 16;                   // bytes per row per plane (16 B pad)
-    static constexpr int PLANE = ROWS * ROWB / 4;              // floats per plane
-    static constexpr int SIZE = PLANES * PLANE;                // floats per tile
-    static constexpr int NP = ROWS * (TK / 8) / NTHREADS;      // pieces per thread
-    static constexpr int NV = 2 * NP;
-    static_assert(NP >= 1 && NP * NTHREADS == ROWS * (TK / 8), "tile must split evenly over the staging threads");
+    static constexpr int ROWB = KC ? 2 * TK + 16 : 2 * ROWS + 64;  // bytes per LDS row per plane
+    static constexpr int PLANE = (KC ? ROWS : TK) * ROWB / 4;      // floats per plane
+    static constexpr int SIZE = PLANES * PLANE;                    // floats per tile
+    static constexpr int NV = ROWS * TK / 4 / NTHREADS;            // 16-byte registers per thread
+    static constexpr int NP = KC ? NV / 2 : NV;                    // pieces per thread
+    static_assert(NV >= 1 && NV * NTHREADS * 4 == ROWS * TK && (!KC || NV % 2 == 0),
+                  "tile must split evenly over the staging threads");
+    static_assert(KC || ROWS % 128 == 0, "the transposed image's bank layout assumes 256-byte rows");
 
+    // KC: piece = (row, 8 k starting at 8 kb); !KC: piece = (k = kb, 4 rows starting at row)
     __device__ static __forceinline__ void piece(int p, int& row, int& kb)
     {
         if (KC) {
             row = p / (TK / 8);
             kb = p % (TK / 8);
         } else {
-            row = p % ROWS;
-            kb = p / ROWS;
+            row = 4 * (p % (ROWS / 4));
+            kb = p / (ROWS / 4);
         }
     }
 
@@ -216,9 +226,9 @@ struct TileB {
         for (int i = 0; i < NP; ++i) {
             int row, kb;
             piece(tid + i * NTHREADS, row, kb);
-            const int gr = row0 + row, gk = k0 + 8 * kb;
-            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
             if (KC) {
+                const int gr = row0 + row, gk = k0 + 8 * kb;
+                f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
                 const float* p = base + (long long)gr * ld + gk;
                 if (interior && vec) {
                     lo = *reinterpret_cast<const f32x4*>(p);
@@ -230,24 +240,21 @@ struct TileB {
                         if (gk + 4 + q < k_end) hi[q] = p[4 + q];
                     }
                 }
+                reg[2 * i] = lo;
+                reg[2 * i + 1] = hi;
             } else {
+                const int gr = row0 + row, gk = k0 + kb;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 const float* p = base + (long long)gk * ld + gr;
-                if (interior) {
+                if (interior && vec) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else if (gk < k_end) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        lo[q] = p[(long long)q * ld];
-                        hi[q] = p[(long long)(4 + q) * ld];
-                    }
-                } else if (gr < rows_total) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (gk + q < k_end) lo[q] = p[(long long)q * ld];
-                        if (gk + 4 + q < k_end) hi[q] = p[(long long)(4 + q) * ld];
-                    }
+                    for (int q = 0; q < 4; ++q)
+                        if (gr + q < rows_total) v[q] = p[q];
                 }
+                reg[i] = v;
             }
-            reg[2 * i] = lo;
-            reg[2 * i + 1] = hi;
         }
     }
 
@@ -259,18 +266,12 @@ struct TileB {
         for (int i = 0; i < NP; ++i) {
             int row, kb;
             piece(tid + i * NTHREADS, row, kb);
-            const int gr = row0 + row, gk = k0 + 8 * kb;
             if (KC) {
-                const float* p = base + (long long)gr * ld + gk;
+                const float* p = base + (long long)(row0 + row) * ld + (k0 + 8 * kb);
                 reg[2 * i] = *reinterpret_cast<const f32x4*>(p);
                 reg[2 * i + 1] = *reinterpret_cast<const f32x4*>(p + 4);
             } else {
-                const float* p = base + (long long)gk * ld + gr;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    reg[2 * i][q] = p[(long long)q * ld];
-                    reg[2 * i + 1][q] = p[(long long)(4 + q) * ld];
-                }
+                reg[i] = *reinterpret_cast<const f32x4*>(base + (long long)(k0 + kb) * ld + (row0 + row));
             }
         }
     }
@@ -281,6 +282,15 @@ struct TileB {
         return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
     }
 
+    // x0, x1 -> their bf16 pair in plane 0 (1, 2) and what is left of them
+    __device__ static __forceinline__ unsigned take_plane(float& x0, float& x1)
+    {
+        const unsigned w = top_halves(x0, x1);
+        x0 -= __uint_as_float(__float_as_uint(x0) & 0xffff0000u);  // exact
+        x1 -= __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        return w;
+    }
+
     __device__ static __forceinline__ void stage(float* s, const f32x4 (&reg)[NV], int tid)
     {
         char* sb = reinterpret_cast<char*>(s);
@@ -288,47 +298,82 @@ struct TileB {
         for (int i = 0; i < NP; ++i) {
             int row, kb;
             piece(tid + i * NTHREADS, row, kb);
-            float x[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                x[q] = reg[2 * i][q];
-                x[4 + q] = reg[2 * i + 1][q];
-            }
-            char* dst = sb + row * ROWB + kb * 16;
-            if (PLANES == 1) {
-                u32x4 w;
+            if (KC) {
+                float x[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    unsigned pk;
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x[2 * q]), "v"(x[2 * q + 1]));
-                    w[q] = pk;
+                    x[q] = reg[2 * i][q];
+                    x[4 + q] = reg[2 * i + 1][q];
                 }
-                *reinterpret_cast<u32x4*>(dst) = w;
+                char* dst = sb + row * ROWB + kb * 16;
+                if (PLANES == 1) {
+                    u32x4 w;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned pk;
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x[2 * q]), "v"(x[2 * q + 1]));
+                        w[q] = pk;
+                    }
+                    *reinterpret_cast<u32x4*>(dst) = w;
+                } else {
+                    u32x4 w0, w1, w2;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w0[q] = take_plane(x[2 * q], x[2 * q + 1]);
+                        w1[q] = take_plane(x[2 * q], x[2 * q + 1]);
+                        w2[q] = top_halves(x[2 * q], x[2 * q + 1]);  // <= 8 bits left
+                    }
+                    *reinterpret_cast<u32x4*>(dst) = w0;
+                    *reinterpret_cast<u32x4*>(dst + PLANE * 4) = w1;
+                    *reinterpret_cast<u32x4*>(dst + 2 * PLANE * 4) = w2;
+                }
             } else {
-                u32x4 w0, w1, w2;
+                float x[4] = {reg[i][0], reg[i][1], reg[i][2], reg[i][3]};
+                char* dst = sb + kb * ROWB + row * 2;
+                if (PLANES == 1) {
+                    u32x2 w;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float a0 = x[2 * q], b0 = x[2 * q + 1];
-                    w0[q] = top_halves(a0, b0);
-                    const float a1 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u);  // exact
-                    const float b1 = b0 - __uint_as_float(__float_as_uint(b0) & 0xffff0000u);
-                    w1[q] = top_halves(a1, b1);
-                    const float a2 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);  // <= 8 bits left
-                    const float b2 = b1 - __uint_as_float(__float_as_uint(b1) & 0xffff0000u);
-                    w2[q] = top_halves(a2, b2);
+                    for (int q = 0; q < 2; ++q) {
+                        unsigned pk;
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(x[2 * q]), "v"(x[2 * q + 1]));
+                        w[q] = pk;
+                    }
+                    *reinterpret_cast<u32x2*>(dst) = w;
+                } else {
+                    u32x2 w0, w1, w2;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        w0[q] = take_plane(x[2 * q], x[2 * q + 1]);
+                        w1[q] = take_plane(x[2 * q], x[2 * q + 1]);
+                        w2[q] = top_halves(x[2 * q], x[2 * q + 1]);
+                    }
+                    *reinterpret_cast<u32x2*>(dst) = w0;
+                    *reinterpret_cast<u32x2*>(dst + PLANE * 4) = w1;
+                    *reinterpret_cast<u32x2*>(dst + 2 * PLANE * 4) = w2;
                 }
-                *reinterpret_cast<u32x4*>(dst) = w0;
-                *reinterpret_cast<u32x4*>(dst + PLANE * 4) = w1;
-                *reinterpret_cast<u32x4*>(dst + 2 * PLANE * 4) = w2;
             }
         }
     }
 
-    // plane pl, row rbase + r, the 8 k values 16*g + 8*h .. +7
+    // plane pl, row rbase + r, the 8 k values 16*g + 8*h .. +7.  (The transposed read needs every lane of the
+    // wave active: it is only called from the block-uniform main loop.)
     __device__ static __forceinline__ bf16x8 frag(const float* s, int pl, int rbase, int g, int r, int h)
     {
-        const char* p = reinterpret_cast<const char*>(s) + pl * (PLANE * 4) + (rbase + r) * ROWB + (2 * g + h) * 16;
-        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+        if (KC) {
+            const char* p = reinterpret_cast<const char*>(s) + pl * (PLANE * 4) + (rbase + r) * ROWB + (2 * g + h) * 16;
+            return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+        } else {
+            // lane (r, h) sits in the 16-lane group 2h + (r >> 4) as lane r & 15: it receives row rbase + r; it
+            // supplies the address of k row (r >> 2) & 3 of the group's 4 x 16 block, columns 4 (r & 3) .. + 3
+            const char* p = reinterpret_cast<const char*>(s) + pl * (PLANE * 4) + (16 * g + 8 * h + ((r >> 2) & 3)) * ROWB +
+                            (rbase + (r & 16) + 4 * (r & 3)) * 2;
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * ROWB));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        }
     }
 };
 
@@ -697,8 +742,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         constexpr int PL = PREC;
         constexpr int DEPTH = 3;  // deeper rings (4, 5) measured no faster
         f32x4 ra[DEPTH][TA::NV], rb[DEPTH][TB::NV];
-        const bool fast = m0 + BM <= Mr && n0 + BN <= a.N && (k_end - k_begin) % KS == 0 && nk > 0 &&
-                          (!AKC || a.vecA) && (!BKC || a.vecB);
+        const bool fast = m0 + BM <= Mr && n0 + BN <= a.N && (k_end - k_begin) % KS == 0 && nk > 0 && a.vecA && a.vecB;
         auto step = [&](auto fast_tag, int kt, auto slot_tag) {
             constexpr bool FAST = decltype(fast_tag)::value;
             constexpr int slot = decltype(slot_tag)::value;
