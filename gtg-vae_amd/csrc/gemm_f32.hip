@@ -1244,7 +1244,8 @@ int gemm_pick_splits(int M, int N, int K, int batch)
     int bm, bn;
     cfg_dims(pick_cfg(M, N, K, batch, EPI_STORE), bm, bn);
     const long long tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-    if (tiles >= 256 || K < 1024) return 1;
+    // (256 tiles are half a round of the 512 resident block slots: still worth cutting K in two)
+    if (tiles > 256 || K < 1024) return 1;
     // one full round of resident blocks (two per CU on the 256 CUs for every configuration that gets here)
     long long want = 512 / tiles;
     const long long maxs = K / 256;

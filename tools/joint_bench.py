@@ -26,6 +26,9 @@ from gtg_vae_amd.parallel import all_reduce_small, init_process_group, local_dev
 B, N, d, hid, V, T = 256, 32, 256, 512, 30522, 40
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 only_trainer = len(sys.argv) > 2 and sys.argv[2] == "trainer"   # just the default-mode trainer (for profiling)
+if len(sys.argv) > 3:          # an experimental build of the library (A/B runs on one box)
+    from gtg_vae_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(sys.argv[3])
 rank, local_rank, world = init_process_group()
 dev = torch.device("cuda", local_device_index(local_rank))
 torch.cuda.set_device(dev)
