@@ -303,21 +303,33 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
     const long long MH = (long long)M * H;
     if (i >= MH) return;
     const int row = (int)(i / H), u0 = (int)(i % H);
-    f32x4 dh = {0.f, 0.f, 0.f, 0.f};
-    if (d_hs) dh += *reinterpret_cast<const f32x4*>(d_hs + i);
-    if (d_extra) dh += *reinterpret_cast<const f32x4*>(d_extra + i);
-    for (int z = 0; z < Z; ++z) dh += *reinterpret_cast<const f32x4*>(slabs + z * MH + i);
-    f32x4 dc = {0.f, 0.f, 0.f, 0.f};
-    if (!first)
-        dc = *reinterpret_cast<const f32x4*>(dc_io + i);
-    else if (d_cT)
-        dc = *reinterpret_cast<const f32x4*>(d_cT + i);
+    // Every load is issued before the first is used.  Optional inputs are read through a stand-in address and
+    // discarded (a branch around a load makes the wave wait for everything in flight at the join).
+    auto opt = [&](const float* p) {
+        const float* q = p ? p + i : c_t + i;
+        asm volatile("" : "+v"(q));
+        return *reinterpret_cast<const f32x4*>(q);
+    };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 v_dhs = opt(d_hs), v_ext = opt(d_extra), v_cp = opt(c_prev);
+    const f32x4 v_dc = opt(first ? d_cT : dc_io);
     const float* grow = gates + (long long)row * 4 * H + u0;
     const f32x4 gi = *reinterpret_cast<const f32x4*>(grow), gf = *reinterpret_cast<const f32x4*>(grow + (long long)H);
     const f32x4 gg = *reinterpret_cast<const f32x4*>(grow + 2ll * H), go = *reinterpret_cast<const f32x4*>(grow + 3ll * H);
     const f32x4 c = *reinterpret_cast<const f32x4*>(c_t + i);
-    f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-    if (c_prev) cp = *reinterpret_cast<const f32x4*>(c_prev + i);
+    f32x4 dh = d_hs ? v_dhs : zero;
+    if (d_extra) dh += v_ext;
+    if (Z == 4) {  // the usual slab count: four loads in flight
+        f32x4 t[4];
+#pragma unroll
+        for (int z = 0; z < 4; ++z) t[z] = *reinterpret_cast<const f32x4*>(slabs + z * MH + i);
+#pragma unroll
+        for (int z = 0; z < 4; ++z) dh += t[z];
+    } else {
+        for (int z = 0; z < Z; ++z) dh += *reinterpret_cast<const f32x4*>(slabs + z * MH + i);
+    }
+    const f32x4 dc = (first && d_cT == nullptr) ? zero : v_dc;
+    const f32x4 cp = c_prev ? v_cp : zero;
     f32x4 di, df, dg, dO, dcp;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
