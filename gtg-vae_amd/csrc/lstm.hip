@@ -31,6 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LT = 64;                        // tile edge (rows of A, rows of B)
 constexpr int LKS = 16;                       // k extent of one k block of the plane layout
+constexpr int LDEPTH = 4;                     // register sets of prefetched fragments per wave
 constexpr int LDC = LT + 4;                   // row pitch of the accumulator tile staged for the epilogue
 
 struct StepArgs {
@@ -89,8 +90,8 @@ __device__ __forceinline__ void store_planes4(__bf16* img, long long plane, int 
 // 64 x 64 tile (four 32 x 32 accumulators) over k blocks w, w + 4, ...  Nothing is shared between waves until
 // the end, so the operands skip LDS: in the k-blocked plane layout the 16 bytes lane (r, h) feeds to an MFMA
 // (row r, k half h) of 32 consecutive rows are one contiguous kilobyte, i.e. an MFMA operand is ONE coalesced
-// 16-byte-per-lane load straight into registers.  Four register sets of fragments rotate: three k blocks
-// (36 KB per wave) are in flight while the 24 MFMAs of the fourth run, consecutive MFMAs go to different
+// 16-byte-per-lane load straight into registers.  LDEPTH register sets of fragments rotate: LDEPTH - 1 k blocks
+// (12 KB each per wave) are in flight while the 24 MFMAs of one run, consecutive MFMAs go to different
 // accumulators, and the loop holds no barrier and no LDS access.  The four partial tiles are summed through
 // LDS by the epilogue.  FWD: the LSTM cell as epilogue; else raw slabs.
 struct Frags {
@@ -164,25 +165,22 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
                         for (int jn = 0; jn < 2; ++jn)
                             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[jn][sum - pa], acc[i][jn], 0, 0, 0);
         };
-        Frags f0{}, f1{}, f2{}, f3{};
-        load(0, f0);
-        load(1, f1);
-        load(2, f2);
+        // LDEPTH register sets rotate: LDEPTH - 1 k blocks are in flight while one is multiplied
+        Frags f[LDEPTH];
+#pragma unroll
+        for (int d = 0; d < LDEPTH - 1; ++d) load(d, f[d]);
         int j = 0;
-        for (; j + 3 < mine; j += 4) {
-            load(j + 3, f3);
-            mma(f0);
-            load(j + 4, f0);
-            mma(f1);
-            load(j + 5, f1);
-            mma(f2);
-            load(j + 6, f2);
-            mma(f3);
+        for (; j + LDEPTH - 1 < mine; j += LDEPTH) {
+#pragma unroll
+            for (int u = 0; u < LDEPTH; ++u) {
+                load(j + LDEPTH - 1 + u, f[(LDEPTH - 1 + u) % LDEPTH]);
+                mma(f[u]);
+            }
         }
-        // at most three blocks are left, and they are the ones f0, f1, f2 hold
-        if (j < mine) mma(f0);
-        if (j + 1 < mine) mma(f1);
-        if (j + 2 < mine) mma(f2);
+        // at most LDEPTH - 1 blocks are left, and they are the ones sets 0 .. LDEPTH - 2 hold
+#pragma unroll
+        for (int u = 0; u < LDEPTH - 1; ++u)
+            if (j + u < mine) mma(f[u]);
     }
 
     // each wave leaves its partial tile in LDS (accumulator register e of lane (r, h) is element (row
