@@ -4,11 +4,11 @@ Mirrors /root/reference/src/text_vae.py:22-132 (``TextModel``, ``DAE``): same
 sub-module names and shapes, hence the same ``state_dict`` keys
 (``embed, proj, E, G, hgen, z2emb``).  Embeddings run on stock PyTorch-ROCm
 kernels.  The LSTMs keep their parameters in ``nn.LSTM`` modules (same
-``state_dict`` keys) but on a GPU, in the default three-plane bf16 matrix
-mode, their forward and backward run through the library's own recurrence
-(``functional.lstm``: one fused product + cell launch per time step); the
-other matrix modes and sizes the recurrence does not take use the stock
-module.  The vocabulary projection with its cross-entropy and arg-max -- most
+``state_dict`` keys) but on a GPU, in the bf16-pipe matrix modes (the default
+three-plane one and plain bf16), their forward and backward run through the
+library's own recurrence (``functional.lstm``: one fused product + cell
+launch per time step); the fp32 matrix mode and sizes the recurrence does
+not take use the stock module.  The vocabulary projection with its cross-entropy and arg-max -- most
 of the branch's arithmetic, 2*1024*vocab per token -- has a HIP path of its
 own, ``decode_loss``: it skips the pad tokens' rows in all three GEMMs and
 never holds more than one copy of the logits.
@@ -50,12 +50,12 @@ class DAE(TextModel):
 
     def run_lstm(self, mod, emb, hidden=None, need_output=True):
         """``mod(emb, hidden)`` for a one-layer ``nn.LSTM``: through functional.lstm, one call per direction, when
-        the input is fp32 on a GPU, the matrix mode is the three-plane bf16 one and the sizes fit; else the stock
+        the input is fp32 on a GPU, the matrix mode is one of the bf16-pipe ones and the sizes fit; else the stock
         module.  With ``need_output`` False the (T, B, dirs*H) output is not assembled (None is returned for it)."""
         T, B, I = emb.shape
         H = mod.hidden_size
         mode = _lib.matrix_mode(getattr(self, "matrix_mode", None))
-        if not (emb.is_cuda and emb.dtype == torch.float32 and mode == _lib.MATRIX_MODES["bf16x3"] and
+        if not (emb.is_cuda and emb.dtype == torch.float32 and mode != _lib.MATRIX_MODES["f32"] and
                 mod.num_layers == 1 and Fn.lstm_applies(T, B, I, H)):
             return mod(emb, hidden)
         outs, hn, cn = [], [], []

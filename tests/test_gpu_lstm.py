@@ -106,6 +106,30 @@ def test_module_routes_through_the_hip_recurrence_and_matches_stock_lstm():
     assert torch.equal(out, m.G(emb)[0])
 
 
+def test_lstm_bf16_mode_stays_close():
+    """matrix mode "bf16": the products over all steps (input projection, dW, dx) run on operands rounded to
+    bf16, the recurrence itself stays on three planes.  Tolerance of that mode: outputs 2e-2 of the largest
+    entry, gradients cosine 0.999."""
+    from gtg_vae_amd import functional as Fn
+    from oracle import textvae_oracle as TO
+
+    T, B, I, H = 12, 40, 64, 128
+    g = torch.Generator().manual_seed(5)
+    w_ih, w_hh, b_ih, b_hh = _params(I, H, 13, 1.0 / H ** 0.5)
+    x = torch.randn(T, B, I, generator=g)
+    d_hs = torch.randn(T, B, H, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    out, _, _ = TO.lstm(*leaves)
+    (out * d_hs).sum().backward()
+    cu = [t.clone().cuda().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    hs, _, _ = Fn.lstm(*cu, matrix_mode="bf16")
+    (hs * d_hs.cuda()).sum().backward()
+    assert _relerr(hs, out) < 2e-2
+    for a, b in zip(cu, leaves):
+        cos = torch.nn.functional.cosine_similarity(a.grad.detach().cpu().flatten().double(), b.grad.flatten().double(), dim=0)
+        assert cos > 0.999, float(cos)
+
+
 def test_lstm_rejects_sizes_it_does_not_take():
     from gtg_vae_amd import _lib
     from gtg_vae_amd import functional as Fn
