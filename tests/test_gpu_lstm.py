@@ -65,6 +65,50 @@ def test_lstm_forward_and_backward_match_oracle(T, B, I, H, reverse, init):
             assert _relerr(a.grad, b.grad) < 1e-4, (name, _relerr(a.grad, b.grad))
 
 
+def test_lstm_random_shapes_match_oracle():
+    """Sixteen random shapes (hidden sizes 64..320, inputs 4..132, batches 1..150 -- ragged against the 64-row
+    tiles --, 1..14 steps, either direction, any subset of the optional inputs and upstream gradients)."""
+    import random
+
+    from gtg_vae_amd import functional as Fn
+    from oracle import textvae_oracle as TO
+
+    rnd = random.Random(20261111)
+    for case in range(16):
+        H = 64 * rnd.randint(1, 5)
+        I = 4 * rnd.randint(1, 33)
+        B = rnd.choice([1, 2, 5, 63, 64, 65, rnd.randint(1, 150)])
+        T = rnd.randint(1, 14)
+        reverse, init = rnd.random() < 0.5, rnd.random() < 0.5
+        use = [rnd.random() < 0.7 for _ in range(3)]   # which of (d_hs, d_hT, d_cT) carry a gradient
+        if not any(use):
+            use[rnd.randrange(3)] = True
+        g = torch.Generator().manual_seed(case)
+        w_ih, w_hh, b_ih, b_hh = _params(I, H, 100 + case, 1.5 / H ** 0.5)
+        x = torch.randn(T, B, I, generator=g)
+        h0 = torch.randn(B, H, generator=g) * 0.5 if init else None
+        c0 = torch.randn(B, H, generator=g) * 0.5 if init else None
+        ups = [torch.randn(T, B, H, generator=g), torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)]
+
+        def run(fn, tensors, inits, dev):
+            res = fn(*tensors, inits[0], inits[1], reverse)
+            return res, sum((r * u.to(dev)).sum() for r, u, on in zip(res, ups, use) if on)
+
+        leaves = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+        li = [t.clone().requires_grad_(True) for t in (h0, c0)] if init else [None, None]
+        want, loss = run(TO.lstm, leaves, li, "cpu")
+        loss.backward()
+        cu = [t.clone().cuda().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+        ci = [t.clone().cuda().requires_grad_(True) for t in (h0, c0)] if init else [None, None]
+        got, gloss = run(Fn.lstm, cu, ci, "cuda")
+        gloss.backward()
+        tag = (case, T, B, I, H, reverse, init, use)
+        for a, b in zip(got, want):
+            assert _relerr(a, b) < 1e-5, tag
+        for a, b in zip(cu + (ci if init else []), leaves + (li if init else [])):
+            assert _relerr(a.grad, b.grad) < 1e-4, (tag, _relerr(a.grad, b.grad))
+
+
 def test_lstm_final_state_only_gradient():
     """The encoder's use (text_vae.py:57-58): only h_n feeds the loss, the output sequence gets no gradient."""
     from gtg_vae_amd import functional as Fn
