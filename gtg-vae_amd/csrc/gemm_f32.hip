@@ -201,17 +201,19 @@ struct TileB {
     static constexpr int PLANE = (KC ? ROWS : TK) * ROWB / 4;      // floats per plane
     static constexpr int SIZE = PLANES * PLANE;                    // floats per tile
     static constexpr int NV = ROWS * TK / 4 / NTHREADS;            // 16-byte registers per thread
-    static constexpr int NP = KC ? NV / 2 : NV;                    // pieces per thread
-    static_assert(NV >= 1 && NV * NTHREADS * 4 == ROWS * TK && (!KC || NV % 2 == 0),
-                  "tile must split evenly over the staging threads");
+    // K-contiguous pieces hold 8 k values (two registers, one 16-byte LDS store per plane) when a thread owns an
+    // even number of registers, else 4 (one register, an 8-byte store)
+    static constexpr int KP = (NV % 2 == 0) ? 8 : 4;
+    static constexpr int NP = KC ? NV * 4 / KP : NV;               // pieces per thread
+    static_assert(NV >= 1 && NV * NTHREADS * 4 == ROWS * TK, "tile must split evenly over the staging threads");
     static_assert(KC || ROWS % 128 == 0, "the transposed image's bank layout assumes 256-byte rows");
 
-    // KC: piece = (row, 8 k starting at 8 kb); !KC: piece = (k = kb, 4 rows starting at row)
+    // KC: piece = (row, KP k starting at KP kb); !KC: piece = (k = kb, 4 rows starting at row)
     __device__ static __forceinline__ void piece(int p, int& row, int& kb)
     {
         if (KC) {
-            row = p / (TK / 8);
-            kb = p % (TK / 8);
+            row = p / (TK / KP);
+            kb = p % (TK / KP);
         } else {
             row = 4 * (p % (ROWS / 4));
             kb = p / (ROWS / 4);
@@ -226,7 +228,19 @@ struct TileB {
         for (int i = 0; i < NP; ++i) {
             int row, kb;
             piece(tid + i * NTHREADS, row, kb);
-            if (KC) {
+            if (KC && KP == 4) {
+                const int gr = row0 + row, gk = k0 + 4 * kb;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                const float* p = base + (long long)gr * ld + gk;
+                if (interior && vec) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else if (gr < rows_total) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (gk + q < k_end) v[q] = p[q];
+                }
+                reg[i] = v;
+            } else if (KC) {
                 const int gr = row0 + row, gk = k0 + 8 * kb;
                 f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
                 const float* p = base + (long long)gr * ld + gk;
@@ -266,7 +280,9 @@ struct TileB {
         for (int i = 0; i < NP; ++i) {
             int row, kb;
             piece(tid + i * NTHREADS, row, kb);
-            if (KC) {
+            if (KC && KP == 4) {
+                reg[i] = *reinterpret_cast<const f32x4*>(base + (long long)(row0 + row) * ld + (k0 + 4 * kb));
+            } else if (KC) {
                 const float* p = base + (long long)(row0 + row) * ld + (k0 + 8 * kb);
                 reg[2 * i] = *reinterpret_cast<const f32x4*>(p);
                 reg[2 * i + 1] = *reinterpret_cast<const f32x4*>(p + 4);
@@ -298,7 +314,7 @@ struct TileB {
         for (int i = 0; i < NP; ++i) {
             int row, kb;
             piece(tid + i * NTHREADS, row, kb);
-            if (KC) {
+            if (KC && KP == 8) {
                 float x[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -328,8 +344,9 @@ struct TileB {
                     *reinterpret_cast<u32x4*>(dst + 2 * PLANE * 4) = w2;
                 }
             } else {
+                // four values: consecutive k of one row (K contiguous) or consecutive rows at one k
                 float x[4] = {reg[i][0], reg[i][1], reg[i][2], reg[i][3]};
-                char* dst = sb + kb * ROWB + row * 2;
+                char* dst = KC ? sb + row * ROWB + kb * 8 : sb + kb * ROWB + row * 2;
                 if (PLANES == 1) {
                     u32x2 w;
 #pragma unroll
@@ -1160,7 +1177,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     planes[2 * total + i] = (unsigned short)(__float_as_uint(x2) >> 16);
 }
 
-enum TileCfg { CFG_128, CFG_64x128, CFG_64, CFG_64_K2, CFG_32_K4, CFG_COUNT };
+enum TileCfg { CFG_128, CFG_64x128, CFG_64, CFG_64_K2, CFG_32_K4, CFG_256x128, CFG_COUNT };
 
 inline TileCfg pick_cfg(int M, int N, int K, int batch, int epi)
 {
@@ -1182,6 +1199,7 @@ inline void cfg_dims(TileCfg c, int& bm, int& bn)
         case CFG_128: bm = 128; bn = 128; break;
         case CFG_64x128: bm = 64; bn = 128; break;
         case CFG_32_K4: bm = 32; bn = 32; break;
+        case CFG_256x128: bm = 256; bn = 128; break;
         default: bm = 64; bn = 64; break;
     }
 }
@@ -1288,7 +1306,17 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
     }
     if (d.epi == EPI_MASK && !d.aux) return set_error(GTG_ERR_INVALID, "gemm: mask epilogue without aux");
 
-    const TileCfg cfg = d.planes ? CFG_128 : pick_cfg(d.M, d.N, d.K, d.batch, d.epi);
+    TileCfg cfg = d.planes ? CFG_128 : pick_cfg(d.M, d.N, d.K, d.batch, d.epi);
+#ifndef GTG_NO_256X128
+    // Large products on the bf16 pipes: a 256x128 tile shared by eight waves (one block per CU) moves a quarter
+    // less operand data per multiply-add than the 128x128 tile, through global memory, the split arithmetic and
+    // the LDS stores alike.  Taken when it still gives every CU at least two tiles (a tail split, if offered, is
+    // not used then: with that many tiles the last round's imbalance is small).
+    if (cfg == CFG_128 && !d.planes && (g_matrix_mode == GTG_MATRIX_BF16X3 || g_matrix_mode == GTG_MATRIX_BF16) &&
+        d.batch == 1 && d.splits <= 1 && d.colsum_part == nullptr && d.epi != EPI_POOL &&
+        (long long)((d.M + 255) / 256) * ((d.N + 127) / 128) >= 512)
+        cfg = CFG_256x128;
+#endif
     int bm, bn;
     cfg_dims(cfg, bm, bn);
     if (d.planes) {
@@ -1396,7 +1424,8 @@ int gemm(const GemmDesc& d, hipStream_t s)
         {"gemm64x128_nt", "gemm64x128_nn", "gemm64x128_tn"},
         {"gemm64_nt", "gemm64_nn", "gemm64_tn"},
         {"gemm64k2_nt", "gemm64k2_nn", "gemm64k2_tn"},
-        {"gemm32k4_nt", "gemm32k4_nn", "gemm32k4_tn"}};
+        {"gemm32k4_nt", "gemm32k4_nn", "gemm32k4_tn"},
+        {"gemm256x128_nt", "gemm256x128_nn", "gemm256x128_tn"}};
     const int lay = d.a_kc ? (d.b_kc ? 0 : 1) : 2;
     // a launch whose row count (":m"), depth (":k") or per-graph extent (":g") is read on the device is tagged so:
     // the dimensions recorded with it are then upper bounds, not the work done
@@ -1406,7 +1435,7 @@ int gemm(const GemmDesc& d, hipStream_t s)
     ProfScope prof(s, tag, (long long)d.M * d.batch, d.N, d.K);
     // the matrix pipe applies to the 128x128 configuration (the MFMA-bound GEMMs); the small-tile
     // configurations are latency-bound and stay on the fp32 pipe
-    const int prec = (cfg == CFG_128) ? g_matrix_mode : 0;
+    const int prec = (cfg == CFG_128 || cfg == CFG_256x128) ? g_matrix_mode : 0;
     int rc;
     switch (cfg) {
         case CFG_128:
@@ -1420,6 +1449,12 @@ int gemm(const GemmDesc& d, hipStream_t s)
                 rc = launch_cfg<128, 128, 2, 2, 1>(k, d.a_kc, d.b_kc, (int)grid, s);
             break;
         case CFG_64x128: rc = launch_cfg<64, 128, 1, 4, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        case CFG_256x128:
+            if (prec == 3)
+                rc = launch_cfg<256, 128, 4, 2, 1, 3>(k, d.a_kc, d.b_kc, (int)grid, s);
+            else
+                rc = launch_cfg<256, 128, 4, 2, 1, 1>(k, d.a_kc, d.b_kc, (int)grid, s);
+            break;
         case CFG_64_K2: rc = launch_cfg<64, 64, 2, 2, 2>(k, d.a_kc, d.b_kc, (int)grid, s); break;
         case CFG_32_K4: rc = launch_cfg<32, 32, 1, 1, 4>(k, d.a_kc, d.b_kc, (int)grid, s); break;
         default: rc = launch_cfg<64, 64, 2, 2, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;

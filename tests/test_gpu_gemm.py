@@ -138,6 +138,8 @@ def test_rows_on_device_mask_epilogue():
 MODE_SHAPES = [  # all large enough for the 128x128 configuration the modes apply to
     ("NT", 8192, 512, 1024), ("NN", 4096, 1024, 512), ("TN", 2048, 2048, 4096),
     ("NT", 5000, 700, 333), ("NN", 5001, 701, 77), ("TN", 2100, 1801, 1003),
+    # at least 512 tiles of 256 x 128: the eight-wave configuration of the bf16 pipes (whole and ragged tiles)
+    ("NT", 8192, 2048, 256), ("NN", 4100, 4100, 130), ("TN", 4096, 4227, 203), ("NT", 16500, 1000, 48),
 ]
 
 
