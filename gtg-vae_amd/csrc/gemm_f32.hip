@@ -1310,11 +1310,12 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
 #ifndef GTG_NO_256X128
     // Large products on the bf16 pipes: a 256x128 tile shared by eight waves (one block per CU) moves a quarter
     // less operand data per multiply-add than the 128x128 tile, through global memory, the split arithmetic and
-    // the LDS stores alike.  Taken when it still gives every CU at least two tiles (a tail split, if offered, is
-    // not used then: with that many tiles the last round's imbalance is small).
+    // the LDS stores alike.  Taken when it still gives every CU at least two tiles; a caller that offers a tail
+    // split (few rounds of tiles, or a row count known only on the device) keeps the 128x128 tile until the
+    // product has eight rounds of the large one, where the last round's imbalance no longer matters.
     if (cfg == CFG_128 && !d.planes && (g_matrix_mode == GTG_MATRIX_BF16X3 || g_matrix_mode == GTG_MATRIX_BF16) &&
         d.batch == 1 && d.splits <= 1 && d.colsum_part == nullptr && d.epi != EPI_POOL &&
-        (long long)((d.M + 255) / 256) * ((d.N + 127) / 128) >= 512)
+        (long long)((d.M + 255) / 256) * ((d.N + 127) / 128) >= (d.tail_ws != nullptr ? 2048 : 512))
         cfg = CFG_256x128;
 #endif
     int bm, bn;

@@ -29,7 +29,7 @@ def timed(fn, reps=30):
     return e0.elapsed_time(e1) / reps
 
 
-for (M, N, K, rows, epi) in ((32832, 1024, 512, 20759, 3), (32832, 512, 1024, 20759, 0)):
+for (M, N, K, rows, epi) in ((32832, 1024, 512, 20759, 3), (32832, 1024, 512, 20759, 0), (32832, 512, 1024, 20759, 0)):
     torch.manual_seed(0)
     A = torch.randn(M, K, device="cuda")
     W = torch.randn(N, K, device="cuda")
