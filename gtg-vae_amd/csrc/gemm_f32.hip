@@ -1313,8 +1313,10 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
     // the LDS stores alike.  Taken when it still gives every CU at least two tiles; a caller that offers a tail
     // split (few rounds of tiles, or a row count known only on the device) keeps the 128x128 tile until the
     // product has eight rounds of the large one, where the last round's imbalance no longer matters.
-    if (cfg == CFG_128 && !d.planes && (g_matrix_mode == GTG_MATRIX_BF16X3 || g_matrix_mode == GTG_MATRIX_BF16) &&
-        d.batch == 1 && d.splits <= 1 && d.colsum_part == nullptr && d.epi != EPI_POOL &&
+    // Measured on the text branch's products: a weight gradient (TN, both operands row-contiguous) gains 7-10 %,
+    // products with a K-contiguous A lose about as much, so only the former take it.
+    if (cfg == CFG_128 && !d.planes && !d.a_kc && !d.b_kc &&
+        (g_matrix_mode == GTG_MATRIX_BF16X3 || g_matrix_mode == GTG_MATRIX_BF16) && d.batch == 1 && d.splits <= 1 && d.colsum_part == nullptr && d.epi != EPI_POOL &&
         (long long)((d.M + 255) / 256) * ((d.N + 127) / 128) >= (d.tail_ws != nullptr ? 2048 : 512))
         cfg = CFG_256x128;
 #endif
