@@ -535,8 +535,10 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         hipLaunchKernelGGL(lstm_slab_sum_kernel, dim3(cell_blocks), dim3(256), 0, s, w.slabs, Z, BH, dh0);
         if (int rc = check_launch("lstm_slab_sum_kernel")) return rc;
     }
-    if (dc0 && hipMemcpyAsync(dc0, w.dc, BH * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return set_error(GTG_ERR_LAUNCH, "lstm_bwd: copy of dc0 failed");
+    if (dc0) {  // a copy as a kernel (one "slab"): the library enqueues no memcpy / memset nodes
+        hipLaunchKernelGGL(lstm_slab_sum_kernel, dim3(cell_blocks), dim3(256), 0, s, w.dc, 1, BH, dc0);
+        if (int rc = check_launch("lstm_slab_sum_kernel")) return rc;
+    }
 
     const int TB = T * B;
     if (int rc = colsum(w.dG, TB, 4 * H, 4 * H, w.cs, db, s)) return rc;
@@ -556,8 +558,8 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = (T - 1) * B;
         g.splits = gemm_pick_splits(4 * H, H, (T - 1) * B, 1); g.slabs = w.gemm_slabs;
         if (int rc = gemm(g, s)) return rc;
-    } else if (hipMemsetAsync(dw_hh, 0, total * sizeof(float), s) != hipSuccess) {
-        return set_error(GTG_ERR_LAUNCH, "lstm_bwd: clearing dW_hh failed");
+    } else if (int rc = clear_i32(reinterpret_cast<int32_t*>(dw_hh), total, s)) {  // one step and no h0 term yet: zero
+        return rc;
     }
     if (h0) {
         g = GemmDesc();
