@@ -233,7 +233,7 @@ int gtg_encoder_fwd(const float* adj, const float* x, const float* W1, const flo
                     const float* b2, int64_t num_graphs, int n, int f, int d, float* h1, float* pooled,
                     int32_t* argmax, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(num_graphs >= 0 && f >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
@@ -321,7 +321,7 @@ int gtg_encoder_bwd(const float* adj, const float* x, const float* W1, const flo
                     const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int f, int d, float* dW1,
                     float* db1, float* dW2, float* db2, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     (void)W1;
     GTG_REQUIRE(num_graphs >= 1 && f >= 1 && d >= 1, "bad size");
@@ -421,7 +421,7 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const floa
                             const float* b2, int64_t num_graphs, int n, int d, int32_t* meta, float* adjc, float* h1c,
                             float* pooled, int32_t* argmax, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
@@ -519,7 +519,7 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
                             const int32_t* argmax, const float* dpooled, int64_t num_graphs, int n, int d, float* dW1,
                             float* db1, float* dW2, float* db2, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
     GTG_REQUIRE(n >= 1 && n <= 64, "n must be in [1, 64]");
@@ -537,7 +537,7 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     // The plane path: in the BF16X3 mode, at sizes where dZ1c = (dT2c W2) masked runs on the 128x128 tiles and dW2
     // needs no fp32 dT2c, the gather writes dT2c straight as the three bf16 planes that GEMM consumes, W2^T is split
     // once, and the GEMM's loop carries no split arithmetic.
-    const bool planes = matrix_mode == GTG_MATRIX_BF16X3 && pool_bwd_gather_planes_applies(n, d) && dw2_sparse_applies(B, n, d, H) &&
+    const bool planes = matrix_mode_split(matrix_mode) && pool_bwd_gather_planes_applies(n, d) && dw2_sparse_applies(B, n, d, H) &&
                         (long long)((rows + 127) / 128) * ((H + 127) / 128) >= 192;
     // dT2c: real rows from the max-pool routing, prototype rows from the graphs whose maximum they won
     if (planes) {
@@ -879,7 +879,7 @@ int gtg_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const flo
                  const float* h0, const float* c0, int T, int B, int I, int H, int reverse, float* hs, float* cs,
                  float* gates, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(T >= 1 && B >= 1 && I >= 1 && H >= 1, "bad size");
     GTG_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hs && cs && gates, "null pointer");
@@ -895,7 +895,7 @@ int gtg_lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const flo
                  int B, int I, int H, int reverse, float* dx, float* dw_ih, float* dw_hh, float* db, float* dh0,
                  float* dc0, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(T >= 1 && B >= 1 && I >= 1 && H >= 1, "bad size");
     GTG_REQUIRE(x && w_ih && w_hh && hs && cs && gates && dw_ih && dw_hh && db, "null pointer");
@@ -925,23 +925,28 @@ int gtg_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
                  int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, void* slabs,
                  size_t slab_bytes, int matrix_mode, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_ACCUM, "unsupported epilogue");
     GemmDesc g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_kc = a_kc != 0; g.b_kc = b_kc != 0; g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux;
+    // workspace: the split-K slabs (when the shape splits) followed by the scratch of the two-plane fp16 mode
+    size_t used = 0;
     if (slabs && !bias && (epilogue == EPI_STORE || epilogue == EPI_ACCUM)) {
         const int sp = gemm_pick_splits(M, N, K, 1);
         if (sp > 1 && (size_t)sp * M * N * sizeof(float) <= slab_bytes) {
             g.splits = sp;
             g.slabs = reinterpret_cast<float*>(slabs);
+            used = (size_t)sp * M * N * sizeof(float);
         }
     }
+    if (slabs && used + GEMM_ABSMAX_BYTES <= slab_bytes)
+        g.absmax_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(slabs) + used);
     return gemm(g, (hipStream_t)stream);
 }
 
-size_t gtg_gemm_splitk_workspace_bytes(int M, int N, int K) { return gemm_splitk_workspace(M, N, K, 1); }
+size_t gtg_gemm_splitk_workspace_bytes(int M, int N, int K) { return gemm_splitk_workspace(M, N, K, 1) + GEMM_ABSMAX_BYTES; }
 
 // GEMM whose row count is read on the device (rows_dev, nullable), with the
 // tail split: C[:min(M,*rows_dev)] = op(A) * op(B).  Test / profiling hook
@@ -950,25 +955,26 @@ size_t gtg_gemm_rows_workspace_bytes(void)
 {
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);
-    return tb + cb;
+    return tb + cb + GEMM_ABSMAX_BYTES;
 }
 
 int gtg_gemm_f32_rows(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
                       int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, const int32_t* rows_dev,
                       int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(epilogue >= EPI_STORE && epilogue <= EPI_ACCUM, "unsupported epilogue");
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);
-    GTG_REQUIRE(ws != nullptr && ws_bytes >= tb + cb, "workspace too small");
+    GTG_REQUIRE(ws != nullptr && ws_bytes >= tb + cb + GEMM_ABSMAX_BYTES, "workspace too small");
     GemmDesc g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_kc = a_kc != 0; g.b_kc = b_kc != 0; g.bias = bias; g.epi = epilogue; g.aux = aux; g.ldaux = ldaux;
     g.m_dev = rows_dev;
     g.tail_ws = reinterpret_cast<float*>(ws);
     g.tail_counters = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + tb);
+    g.absmax_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + tb + cb);
     GTG_TRY(clear_i32(g.tail_counters, (int64_t)(cb / sizeof(int32_t)), (hipStream_t)stream));
     return gemm(g, (hipStream_t)stream);
 }
@@ -1010,14 +1016,14 @@ size_t gtg_proj_ce_fwd_workspace_bytes(int64_t rows, int k, int vocab)
     (void)rows; (void)k; (void)vocab;
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);
-    return align256(tb) + align256(cb);
+    return align256(tb) + align256(cb) + align256(GEMM_ABSMAX_BYTES);
 }
 
 int gtg_proj_ce_fwd(const float* H, const float* W, const float* bias, const int64_t* targets, int64_t rows, int k,
                     int vocab, int64_t padidx, float* loss, int32_t* pred, int32_t* rowmap, float* Hc, float* P,
                     int64_t ldp, int matrix_mode, void* ws, size_t ws_bytes, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(rows >= 0 && k > 0 && vocab > 0, "bad size");
     GTG_REQUIRE(rows <= (1 << 30) / 2, "too many rows");
@@ -1031,6 +1037,7 @@ int gtg_proj_ce_fwd(const float* H, const float* W, const float* bias, const int
     gemm_tail_workspace(&tb, &cb);
     float* tail_ws = reinterpret_cast<float*>(ws);
     int32_t* tail_counters = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + align256(tb));
+    float* absmax = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + align256(tb) + align256(cb));
 
     GTG_TRY(ce_rowmap(targets, rows, padidx, rowmap, loss, pred, s));
     GTG_TRY(ce_rows(0, H, nullptr, rowmap, rows, k, Hc, s));
@@ -1043,6 +1050,7 @@ int gtg_proj_ce_fwd(const float* H, const float* W, const float* bias, const int
     g.bias = bias;
     g.m_dev = rowmap;
     g.tail_ws = tail_ws; g.tail_counters = tail_counters;
+    g.absmax_ws = absmax;
     GTG_TRY(gemm(g, s));
     return ce_softmax(P, ldp, vocab, targets, rowmap, rows, loss, pred, s);
 }
@@ -1061,7 +1069,7 @@ size_t gtg_proj_ce_bwd_workspace_bytes(int64_t rows, int k, int vocab)
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);
     const int sp = proj_ce_dh_splits(rows, k);
-    return align256(tb) + align256(cb) + 2 * align256((size_t)rows * k * sizeof(float)) +
+    return align256(tb) + align256(cb) + align256(GEMM_ABSMAX_BYTES) + 2 * align256((size_t)rows * k * sizeof(float)) +
            align256(ce_bias_grad_workspace(vocab)) + (sp > 1 ? align256((size_t)sp * rows * k * sizeof(float)) : 0);
 }
 
@@ -1069,7 +1077,7 @@ int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, c
                     int64_t ldp, int64_t rows, int k, int vocab, float* dH, float* dW, float* db, int matrix_mode,
                     void* ws, size_t ws_bytes, void* stream)
 {
-    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16 or _BF16X3");
+    GTG_REQUIRE(matrix_mode_valid(matrix_mode), "matrix_mode must be GTG_MATRIX_F32, _BF16, _F16X2 or _BF16X3");
     MatrixModeScope matrix_scope(matrix_mode);
     GTG_REQUIRE(rows >= 0 && k > 0 && vocab > 0, "bad size");
     GTG_REQUIRE(rows <= (1 << 30) / 2, "too many rows");
@@ -1089,6 +1097,7 @@ int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, c
     char* w = reinterpret_cast<char*>(ws);
     float* tail_ws = reinterpret_cast<float*>(w); w += align256(tb);
     int32_t* tail_counters = reinterpret_cast<int32_t*>(w); w += align256(cb);
+    float* absmax = reinterpret_cast<float*>(w); w += align256(GEMM_ABSMAX_BYTES);
     float* Hs = reinterpret_cast<float*>(w); w += align256((size_t)rows * k * sizeof(float));
     float* dHc = reinterpret_cast<float*>(w); w += align256((size_t)rows * k * sizeof(float));
     float* db_partial = reinterpret_cast<float*>(w); w += align256(ce_bias_grad_workspace(vocab));
@@ -1104,6 +1113,8 @@ int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, c
         g.C = dW; g.ldc = k;
         g.M = vocab; g.N = k; g.K = (int)rows;
         g.k_dev = count;
+        g.absmax_ws = absmax;
+        g.a_bound = 1.f;  // probabilities minus one-hot
         GTG_TRY(gemm(g, s));
     }
     if (db) GTG_TRY(ce_bias_grad(P, ldp, vocab, gloss, rowmap, rows, db_partial, db, s));
@@ -1122,6 +1133,8 @@ int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, c
         } else {
             g.tail_ws = tail_ws; g.tail_counters = tail_counters;
         }
+        g.absmax_ws = absmax;
+        g.a_bound = 1.f;
         GTG_TRY(gemm(g, s));
         GTG_TRY(ce_rows(2, dHc, gloss, rowmap, rows, k, dH, s));
     }

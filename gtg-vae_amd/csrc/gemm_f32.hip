@@ -56,7 +56,12 @@ struct KArgs {
     // PREC 4: A and B point at bf16 plane images [3][K/16][rows][16]; lda / ldb are then the `rows` extents of the
     // images and these the distances between planes, in bf16 elements
     long long planeA, planeB;
+    // PREC 2: ABSMAX_PARTS partial maxima of |A| followed by as many of |B| (absmax_pair_kernel), from which every
+    // block derives the two power-of-two operand scales
+    const float* absmax;
 };
+
+constexpr int ABSMAX_PARTS = GEMM_ABSMAX_PARTS;
 
 // Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).
 // Give each XCD a contiguous run of tile ids so that the tiles that re-read
@@ -183,6 +188,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //               8 significant bits each (fp32 has 24), so that the six products
 //               h_i*h_j, i + j <= 2, summed in fp32 reproduce the fp32 product
 //               to ~2^-22 relative.
+//   PLANES = 2: the planes hold fp16, not bf16: x * scale = h0 + h1 + (at most 2^-22 of it), h0 the value
+//               rounded to nearest, h1 what is left rounded to nearest (11 significant bits each and the sign
+//               of the remainder); the three products h0*h0, h0*h1, h1*h0 reproduce the fp32 product as
+//               closely as the six of PLANES = 3.  `scale` is a power of two that puts the operand's largest
+//               magnitude just below 2^14 (fp16 reaches 65504), so nothing overflows and only values 2^-28 of
+//               the largest and smaller lose relative precision.
 // Either way a lane's MFMA fragment is (row r, 8 consecutive k).
 //   KC  (K contiguous in memory): every thread owns pieces of (row, 8 k), two 16-byte loads each; LDS image
 //        per plane [ROWS][TK bf16 + 16 B pad], a fragment is one conflict-free ds_read_b128.
@@ -307,7 +318,23 @@ struct TileB {
         return w;
     }
 
-    __device__ static __forceinline__ void stage(float* s, const f32x4 (&reg)[NV], int tid)
+    // x0, x1 -> their fp16 pair rounded to nearest and what is left of them (exact)
+    __device__ static __forceinline__ unsigned take_half(float& x0, float& x1)
+    {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        const f16x2 hpair = {(_Float16)x0, (_Float16)x1};
+        x0 -= (float)hpair[0];
+        x1 -= (float)hpair[1];
+        return __builtin_bit_cast(unsigned, hpair);
+    }
+    __device__ static __forceinline__ unsigned round_half(float x0, float x1)
+    {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        const f16x2 hpair = {(_Float16)x0, (_Float16)x1};
+        return __builtin_bit_cast(unsigned, hpair);
+    }
+
+    __device__ static __forceinline__ void stage(float* s, const f32x4 (&reg)[NV], int tid, float scale = 1.f)
     {
         char* sb = reinterpret_cast<char*>(s);
 #pragma unroll
@@ -331,6 +358,16 @@ struct TileB {
                         w[q] = pk;
                     }
                     *reinterpret_cast<u32x4*>(dst) = w;
+                } else if (PLANES == 2) {
+                    u32x4 w0, w1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float y0 = x[2 * q] * scale, y1 = x[2 * q + 1] * scale;
+                        w0[q] = take_half(y0, y1);
+                        w1[q] = round_half(y0, y1);
+                    }
+                    *reinterpret_cast<u32x4*>(dst) = w0;
+                    *reinterpret_cast<u32x4*>(dst + PLANE * 4) = w1;
                 } else {
                     u32x4 w0, w1, w2;
 #pragma unroll
@@ -356,6 +393,16 @@ struct TileB {
                         w[q] = pk;
                     }
                     *reinterpret_cast<u32x2*>(dst) = w;
+                } else if (PLANES == 2) {
+                    u32x2 w0, w1;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float y0 = x[2 * q] * scale, y1 = x[2 * q + 1] * scale;
+                        w0[q] = take_half(y0, y1);
+                        w1[q] = round_half(y0, y1);
+                    }
+                    *reinterpret_cast<u32x2*>(dst) = w0;
+                    *reinterpret_cast<u32x2*>(dst + PLANE * 4) = w1;
                 } else {
                     u32x2 w0, w1, w2;
 #pragma unroll
@@ -414,6 +461,17 @@ struct PlaneStage {
     static constexpr int PIECES = STAGE_BYTES / 1024;           // wave instructions per stage
 };
 
+// One 32x32x16 product on 16-bit fragments: bf16, or fp16 (the fragments are carried as bf16x8 bit patterns).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_16bit(bf16x8 x, bf16x8 y, f32x16 c)
+{
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+}
+
 // WAVES_M x WAVES_N waves share one BM x BN tile; KG such wave groups split the
 // block's K range between them (each with its own LDS buffers and its own
 // loads) and their accumulators are summed through LDS, in group order, before
@@ -422,14 +480,15 @@ struct PlaneStage {
 // tiles to hide it behind other blocks.
 // PREC selects the matrix pipe: 0 = fp32 operands (v_mfma_f32_32x32x2_f32), 1 = operands rounded to
 // bf16, 3 = the exact three-plane bf16 split with six products per k step (both on
-// v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate), 2 = operands scaled by a power of two and split into two fp16
+// planes, three products per k step (v_mfma_f32_32x32x16_f16), the result scaled back.
 // LDS floats of one block: the operand double buffers of every wave group, reused by the epilogue to
 // stage the accumulators.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC, int PREC>
 constexpr int gemm_smem_floats()
 {
     constexpr int GT = 64 * WAVES_M * WAVES_N;
-    constexpr int KS = (PREC == 3) ? 16 : BK;
+    constexpr int KS = (PREC == 3 || PREC == 2) ? 16 : BK;
     constexpr int TPL = (PREC == 0 || PREC == 4) ? 1 : PREC;
     using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, TPL, KS>>::type;
     using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, TPL, KS>>::type;
@@ -450,7 +509,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
     constexpr int GT = 64 * WAVES_M * WAVES_N;  // threads of one wave group
     constexpr int GW = WAVES_M * WAVES_N;
     // k extent of one pipeline step: the three-plane tiles take 16 so that two blocks still fit a CU's LDS
-    constexpr int KS = (PREC == 3 || PREC == 4) ? 16 : BK;
+    constexpr int KS = (PREC == 3 || PREC == 4 || PREC == 2) ? 16 : BK;
     constexpr int TPL = (PREC == 0 || PREC == 4) ? 1 : PREC;  // planes of the register-staged bf16 tiles
     using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, TPL, KS>>::type;
     using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, TPL, KS>>::type;
@@ -557,6 +616,39 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // PREC 2: the power of two that puts each operand's largest magnitude in [2^13, 2^14), and its inverse.
+    // Every block reduces the same partial maxima (left by the launch before this one) in the same order.
+    float sc_a = 1.f, sc_b = 1.f, inv_a = 1.f, inv_b = 1.f;
+    if constexpr (PREC == 2) {
+        static_assert(KG == 1, "the scale prologue is written for one wave group");
+        float ma = 0.f, mb = 0.f;
+#pragma unroll
+        for (int i = 0; i < ABSMAX_PARTS / GT; ++i) {
+            ma = fmaxf(ma, a.absmax[i * GT + tid]);
+            mb = fmaxf(mb, a.absmax[ABSMAX_PARTS + i * GT + tid]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ma = fmaxf(ma, __shfl_xor(ma, o));
+            mb = fmaxf(mb, __shfl_xor(mb, o));
+        }
+        if (lane == 0) {
+            smem[2 * wave] = ma;
+            smem[2 * wave + 1] = mb;
+        }
+        __syncthreads();
+        ma = smem[0];
+        mb = smem[1];
+#pragma unroll
+        for (int w = 1; w < GW; ++w) {
+            ma = fmaxf(ma, smem[2 * w]);
+            mb = fmaxf(mb, smem[2 * w + 1]);
+        }
+        __syncthreads();  // before the first tile is staged over these words
+        f16x2_scale(ma, sc_a, inv_a);
+        f16x2_scale(mb, sc_b, inv_b);
+    }
 
     if constexpr (PREC == 4) {
         static_assert(KG == 1 && WAVES_M * WAVES_N == 4, "the plane pipeline is written for four waves");
@@ -784,14 +876,20 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j],
-                                                                                  0, 0, 0);
+                                acc[i][j] = mfma_16bit<PREC == 2>(fa[i][pa], fb[j][sum - pa], acc[i][j]);
                 if (g == 0) {
                     // tile kt + 1 waits in `slot`; staging is unconditional (past the last tile it rewrites
                     // a buffer nobody reads again)
-                    TA::stage((kt & 1) ? sA0 : sA1, ra[slot], tid);
-                    TB::stage((kt & 1) ? sB0 : sB1, rb[slot], tid);
+                    TA::stage((kt & 1) ? sA0 : sA1, ra[slot], tid, sc_a);
+                    TB::stage((kt & 1) ? sB0 : sB1, rb[slot], tid, sc_b);
                     if (FAST) {
+                        if (PL == 2) {
+#pragma unroll
+                            for (int q = 0; q < 3 * TM * TN; ++q) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                            }
+                        }
                         if (PL == 3) {
                             // one MFMA, then four of the split's vector instructions in its shadow
 #pragma unroll
@@ -827,8 +925,8 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
                 }
             }
             if (nk > 0) {
-                TA::stage(sA0, ra[0], tid);
-                TB::stage(sB0, rb[0], tid);
+                TA::stage(sA0, ra[0], tid, sc_a);
+                TB::stage(sB0, rb[0], tid, sc_b);
                 if (FAST) {
                     const int k0 = k_begin + min(DEPTH, nk - 1) * KS;
                     TA::fetch_fast(ra[0], A, a.lda, m0, k0, tid);
@@ -856,6 +954,17 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
             run(std::true_type());
         else
             run(std::false_type());
+    }
+
+    if constexpr (PREC == 2) {
+        // undo the operand scales (two multiplications by powers of two: exact, and neither factor can leave
+        // the normal range the way their product could)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] * inv_a) * inv_b;
     }
 
     // ---- epilogue.  Accumulator register e of lane (r,h) is element
@@ -1177,6 +1286,65 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     planes[2 * total + i] = (unsigned short)(__float_as_uint(x2) >> 16);
 }
 
+// Partial maxima of |A| and |B| for the two-plane fp16 path: blocks [0, ABSMAX_PARTS) walk operand A, the rest
+// operand B; every block writes its maximum (0 when it has no rows), so the output needs no clearing and the
+// result does not depend on the order the blocks run in.  An operand is `rows` x `cols` with leading dimension
+// `ld`, either extent optionally capped by a count in device memory (what lies past it is never read).
+struct AbsmaxJob {
+    const float* p;
+    long long ld;
+    int rows, cols;
+    const int* rows_dev;
+    const int* cols_dev;
+    float bound;  // > 0: the caller's bound on the operand's magnitudes is taken instead of a pass over it
+};
+
+__global__ __launch_bounds__(256) void absmax_pair_kernel(const AbsmaxJob ja, const AbsmaxJob jb, float* __restrict__ out)
+{
+    __shared__ float sm[4];
+    const bool second = (int)blockIdx.x >= ABSMAX_PARTS;
+    const AbsmaxJob j = second ? jb : ja;
+    const int part = (int)blockIdx.x - (second ? ABSMAX_PARTS : 0), tid = threadIdx.x;
+    if (j.bound > 0.f) {
+        if (tid == 0) out[blockIdx.x] = j.bound;
+        return;
+    }
+    int rows = j.rows, cols = j.cols;
+    if (j.rows_dev) rows = min(rows, j.rows_dev[0]);
+    if (j.cols_dev) cols = min(cols, j.cols_dev[0]);
+    const bool vec = (j.ld % 4 == 0) && (reinterpret_cast<uintptr_t>(j.p) & 15) == 0;
+    // threads per row: enough for 16 bytes each, a power of two up to the block; the block takes 256 / tpr rows
+    // a pass, four passes' loads in flight together
+    int tpr = 1;
+    while (tpr < 256 && tpr * 4 < cols) tpr <<= 1;
+    const int rpb = 256 / tpr, tr = tid / tpr, tc = tid % tpr;
+    const int c4 = vec ? (cols & ~3) : 0;
+    const long long pass = (long long)ABSMAX_PARTS * rpb;
+    float m = 0.f;
+    for (int c = tc * 4; c < c4; c += tpr * 4) {
+        long long row = (long long)part * rpb + tr;
+        for (; row + 3 * pass < rows; row += 4 * pass) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(j.p + (row + u * pass) * j.ld + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
+        }
+        for (; row < rows; row += pass) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(j.p + row * j.ld + c);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+    for (long long row = (long long)part * rpb + tr; row < rows; row += pass)
+        for (int c = c4 + tc; c < cols; c += tpr) m = fmaxf(m, fabsf(j.p[row * j.ld + c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) sm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) out[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
 enum TileCfg { CFG_128, CFG_64x128, CFG_64, CFG_64_K2, CFG_32_K4, CFG_256x128, CFG_COUNT };
 
 inline TileCfg pick_cfg(int M, int N, int K, int batch, int epi)
@@ -1249,6 +1417,21 @@ int split_planes(const float* src, long long rows, long long cols, long long ld,
     return check_launch("split_planes_kernel");
 }
 
+int absmax_partials(const float* x, long long rows, long long cols, long long ld, float* out, hipStream_t s)
+{
+    if (rows > 0x7fffffffLL || cols > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "absmax: array too large");
+    AbsmaxJob ja, jb;
+    ja.p = x;
+    ja.ld = ld;
+    ja.rows = (int)rows;
+    ja.cols = (int)cols;
+    ja.rows_dev = ja.cols_dev = nullptr;
+    ja.bound = 0.f;
+    jb = ja;
+    hipLaunchKernelGGL(absmax_pair_kernel, dim3(ABSMAX_PARTS), dim3(256), 0, s, ja, jb, out);  // operand A's blocks only
+    return check_launch("absmax_pair_kernel");
+}
+
 void gemm_tail_workspace(size_t* ws_bytes, size_t* counter_bytes)
 {
     const size_t slots = 1024;  // upper bound on tail_slots(): sized without touching the device
@@ -1316,7 +1499,7 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
     // Measured on the text branch's products: a weight gradient (TN, both operands row-contiguous) gains 7-10 %,
     // products with a K-contiguous A lose about as much, so only the former take it.
     if (cfg == CFG_128 && !d.planes && !d.a_kc && !d.b_kc &&
-        (g_matrix_mode == GTG_MATRIX_BF16X3 || g_matrix_mode == GTG_MATRIX_BF16) && d.batch == 1 && d.splits <= 1 && d.colsum_part == nullptr && d.epi != EPI_POOL &&
+        (g_matrix_mode == GTG_MATRIX_BF16X3 || g_matrix_mode == GTG_MATRIX_BF16 || g_matrix_mode == GTG_MATRIX_F16X2) && d.batch == 1 && d.splits <= 1 && d.colsum_part == nullptr && d.epi != EPI_POOL &&
         (long long)((d.M + 255) / 256) * ((d.N + 127) / 128) >= (d.tail_ws != nullptr ? 2048 : 512))
         cfg = CFG_256x128;
 #endif
@@ -1333,6 +1516,7 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
     KArgs& k = p.k;
     k.planeA = d.planeA;
     k.planeB = d.planeB;
+    k.absmax = d.absmax_ws;
     k.A = d.A;
     k.B = d.B;
     k.C = d.C;
@@ -1438,7 +1622,33 @@ int gemm(const GemmDesc& d, hipStream_t s)
     ProfScope prof(s, tag, (long long)d.M * d.batch, d.N, d.K);
     // the matrix pipe applies to the 128x128 configuration (the MFMA-bound GEMMs); the small-tile
     // configurations are latency-bound and stay on the fp32 pipe
-    const int prec = (cfg == CFG_128 || cfg == CFG_256x128) ? g_matrix_mode : 0;
+    int prec = (cfg == CFG_128 || cfg == CFG_256x128) ? g_matrix_mode : 0;
+    if (prec == GTG_MATRIX_F16X2 && !d.planes) {
+        // the two-plane fp16 split needs the operands' largest magnitudes first; a caller without the scratch
+        // for them, and the batched forms, get the three-plane bf16 split (the same accuracy class)
+        if (d.absmax_ws == nullptr || d.batch != 1 || d.batch_dim != nullptr || d.batch_off != nullptr) {
+            prec = GTG_MATRIX_BF16X3;
+        } else {
+            AbsmaxJob ja, jb;
+            ja.p = d.A;
+            ja.ld = d.lda;
+            ja.rows = d.a_kc ? d.M : d.K;
+            ja.cols = d.a_kc ? d.K : d.M;
+            ja.rows_dev = d.a_kc ? d.m_dev : d.k_dev;
+            ja.cols_dev = d.a_kc ? d.k_dev : d.m_dev;
+            ja.bound = d.a_bound;
+            jb.bound = d.b_bound;
+            jb.p = d.B;
+            jb.ld = d.ldb;
+            jb.rows = d.b_kc ? d.N : d.K;
+            jb.cols = d.b_kc ? d.K : d.N;
+            jb.rows_dev = d.b_kc ? nullptr : d.k_dev;
+            jb.cols_dev = d.b_kc ? d.k_dev : nullptr;
+            ProfScope prof_absmax(s, "absmax_pair", (long long)d.M, d.N, d.K);
+            hipLaunchKernelGGL(absmax_pair_kernel, dim3(2 * ABSMAX_PARTS), dim3(256), 0, s, ja, jb, d.absmax_ws);
+            if (int rc0 = check_launch("absmax_pair_kernel")) return rc0;
+        }
+    }
     int rc;
     switch (cfg) {
         case CFG_128:
@@ -1446,6 +1656,8 @@ int gemm(const GemmDesc& d, hipStream_t s)
                 rc = launch_planes(k, (int)grid, s);
             else if (prec == 3)
                 rc = launch_cfg<128, 128, 2, 2, 1, 3>(k, d.a_kc, d.b_kc, (int)grid, s);
+            else if (prec == 2)
+                rc = launch_cfg<128, 128, 2, 2, 1, 2>(k, d.a_kc, d.b_kc, (int)grid, s);
             else if (prec == 1)
                 rc = launch_cfg<128, 128, 2, 2, 1, 1>(k, d.a_kc, d.b_kc, (int)grid, s);
             else
@@ -1455,6 +1667,8 @@ int gemm(const GemmDesc& d, hipStream_t s)
         case CFG_256x128:
             if (prec == 3)
                 rc = launch_cfg<256, 128, 4, 2, 1, 3>(k, d.a_kc, d.b_kc, (int)grid, s);
+            else if (prec == 2)
+                rc = launch_cfg<256, 128, 4, 2, 1, 2>(k, d.a_kc, d.b_kc, (int)grid, s);
             else
                 rc = launch_cfg<256, 128, 4, 2, 1, 1>(k, d.a_kc, d.b_kc, (int)grid, s);
             break;

@@ -84,7 +84,31 @@ struct GemmDesc {
     // K a multiple of 16, no split-K; m_dev, the tail split, every store epilogue and colsum_part apply.
     bool planes = false;
     long long planeA = 0, planeB = 0;
+    // GTG_MATRIX_F16X2 on the 128x128 / 256x128 configurations: GEMM_ABSMAX_BYTES of device scratch for the
+    // operands' partial maxima (written by a launch of its own right before the GEMM's; calls on one stream may
+    // share it).  Without it such a product runs the three-plane bf16 split instead.
+    float* absmax_ws = nullptr;
+    // optional: a bound the caller knows on the magnitudes of A / B (> 0), which saves that operand's pass
+    float a_bound = 0.f, b_bound = 0.f;
 };
+constexpr int GEMM_ABSMAX_PARTS = 1024;
+constexpr size_t GEMM_ABSMAX_BYTES = 2 * GEMM_ABSMAX_PARTS * sizeof(float);
+// GEMM_ABSMAX_PARTS partial maxima of |x| over a (rows, cols) fp32 array with leading dimension ld, written to
+// out[0 .. GEMM_ABSMAX_PARTS) (every entry is written: no clearing needed)
+int absmax_partials(const float* x, long long rows, long long cols, long long ld, float* out, hipStream_t s);
+
+#if defined(__HIPCC__)
+// The power of two that puts a largest magnitude `mx` into [2^13, 2^14) -- where fp16 (up to 65504) has room for
+// the rounding of every element and of sums the matrix pipe forms before its fp32 accumulation -- and its
+// inverse; both stay normal numbers whatever mx is (zero, subnormal and huge maxima are clamped).
+__device__ __forceinline__ void f16x2_scale(float mx, float& scale, float& inverse)
+{
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);  // biased exponent
+    e = e < 14 ? 14 : (e > 254 ? 254 : e);
+    scale = __uint_as_float((unsigned)(267 - e) << 23);    // 2^(13 - (e - 127))
+    inverse = __uint_as_float((unsigned)(e - 13) << 23);   // 2^((e - 127) - 13)
+}
+#endif
 inline int gemm_colsum_rows(int M) { return 2 * ((M + 127) / 128); }
 
 // Matrix pipe of the MFMA-bound (128x128-tile) GEMMs issued by the calling thread: GTG_MATRIX_F32
@@ -97,7 +121,12 @@ struct MatrixModeScope {
     explicit MatrixModeScope(int mode) : prev(g_matrix_mode) { g_matrix_mode = mode; }
     ~MatrixModeScope() { g_matrix_mode = prev; }
 };
-inline bool matrix_mode_valid(int m) { return m == GTG_MATRIX_F32 || m == GTG_MATRIX_BF16 || m == GTG_MATRIX_BF16X3; }
+inline bool matrix_mode_valid(int m)
+{
+    return m == GTG_MATRIX_F32 || m == GTG_MATRIX_BF16 || m == GTG_MATRIX_BF16X3 || m == GTG_MATRIX_F16X2;
+}
+// the modes whose results carry fp32-level error through split operands on the 16-bit matrix pipe
+inline bool matrix_mode_split(int m) { return m == GTG_MATRIX_BF16X3 || m == GTG_MATRIX_F16X2; }
 
 // Tail-split workspace: *ws_bytes of float slabs and *counter_bytes of int32 counters.
 void gemm_tail_workspace(size_t* ws_bytes, size_t* counter_bytes);

@@ -17,6 +17,11 @@
 //     large products afterwards, planes for the recurrence), then dh_{t-1} += dG_t W_hh with K = 4H cut into
 //     slabs so that the launch again has a block per CU; the slabs are summed by the next step's pointwise
 //     kernel.
+//   * GTG_MATRIX_F16X2 (hidden sizes up to 1024): the recurrence's operands are two fp16 planes instead, every
+//     operand row scaled by a power of two (h: |h| < 1, so 2^13 for every row; an initial state and the gate
+//     gradients: from the row's largest magnitude, found by the kernel that writes the planes; W_hh: one scale
+//     from its largest magnitude), three products per multiply-add, the product scaled back in the epilogue:
+//     the same error with half the matrix instructions and two thirds of the operand bytes.
 #include "gtg_internal.h"
 
 namespace gtg {
@@ -28,14 +33,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+constexpr float H_SCALE = 8192.f, H_INV = 1.f / 8192.f;  // fp16 planes of a hidden state: |h| < 1
 constexpr int LT = 64;                        // tile edge (rows of A, rows of B)
 constexpr int LKS = 16;                       // k extent of one k block of the plane layout
 constexpr int LDEPTH = 4;                     // register sets of prefetched fragments per wave
 constexpr int LDC = LT + 4;                   // row pitch of the accumulator tile staged for the epilogue
 
 struct StepArgs {
-    const __bf16* A;      // [3][K/16][rowsA][16]
+    const __bf16* A;      // [3][K/16][rowsA][16] bf16, or [2][K/16][rowsA][16] fp16
     const __bf16* B;      // [3][K/16][rowsB][16]
     long long planeA, planeB;
     int rowsA, rowsB;
@@ -52,6 +60,11 @@ struct StepArgs {
     int rows_h;
     // backward epilogue
     float* slabs;         // [gridDim.z][M][N]
+    // fp16 planes: the product is multiplied by A's inverse row scale (per row, or one value for all when the
+    // array is null) and by B's inverse scale (a device scalar)
+    const float* inv_a_rows;
+    float inv_a_const;
+    const float* inv_b;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -83,6 +96,25 @@ __device__ __forceinline__ void store_planes4(__bf16* img, long long plane, int 
     *reinterpret_cast<u32x2*>(dst + 2 * plane) = p2;
 }
 
+// the same for two fp16 planes of x * scale: the value rounded to nearest, then what is left rounded to nearest
+__device__ __forceinline__ void store_planes4h(__bf16* img, long long plane, int rows, int row, int k0, const f32x4 x, float scale)
+{
+    u32x2 p0, p1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float a0 = x[2 * q] * scale, b0 = x[2 * q + 1] * scale;
+        const f16x2 hi = {(_Float16)a0, (_Float16)b0};
+        a0 -= (float)hi[0];
+        b0 -= (float)hi[1];
+        const f16x2 lo = {(_Float16)a0, (_Float16)b0};
+        p0[q] = __builtin_bit_cast(unsigned, hi);
+        p1[q] = __builtin_bit_cast(unsigned, lo);
+    }
+    __bf16* dst = img + ((long long)(k0 >> 4) * rows + row) * 16 + (k0 & 15);
+    *reinterpret_cast<u32x2*>(dst) = p0;
+    *reinterpret_cast<u32x2*>(dst + plane) = p1;
+}
+
 // C tile (64 x 64) = A rows [m0, m0+64) x B rows [n0, n0+64) over k blocks [kb0, kb0 + nk).
 //
 // A block is alone on its CU (a block per CU fills the chip) with one wave per SIMD, so nothing but the wave
@@ -94,11 +126,13 @@ __device__ __forceinline__ void store_planes4(__bf16* img, long long plane, int 
 // (12 KB each per wave) are in flight while the 24 MFMAs of one run, consecutive MFMAs go to different
 // accumulators, and the loop holds no barrier and no LDS access.  The four partial tiles are summed through
 // LDS by the epilogue.  FWD: the LSTM cell as epilogue; else raw slabs.
+// NPL = 3: bf16 planes, six products; NPL = 2: fp16 planes, three products and the scales in the epilogue.
+template <int NPL>
 struct Frags {
-    bf16x8 a[2][3], b[2][3];  // [32-row block][plane]
+    bf16x8 a[2][NPL], b[2][NPL];  // [32-row block][plane]
 };
 
-template <bool FWD>
+template <bool FWD, int NPL>
 __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
 {
     constexpr int WAVE_LDS = LT * LDC * 4;  // a wave's partial tile
@@ -143,30 +177,35 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
             pB[i] = a.B + ((long long)(kb0 + wave) * a.rowsB + min(n0 + 32 * i + r, a.N - 1)) * LKS + h * 8;
         }
         const long long stepA = 4ll * a.rowsA * LKS, stepB = 4ll * a.rowsB * LKS;  // to this wave's next k block
-        auto load = [&](int j, Frags& f) {
+        auto load = [&](int j, Frags<NPL>& f) {
             const int jj = min(j, mine - 1);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     f.a[i][pl] = *reinterpret_cast<const bf16x8*>(pA[i] + pl * a.planeA + jj * stepA);
                     f.b[i][pl] = *reinterpret_cast<const bf16x8*>(pB[i] + pl * a.planeB + jj * stepB);
                 }
         };
-        // products of plane pairs (pa, pb) with pa + pb <= 2, the small ones first
-        auto mma = [&](const Frags& f) {
+        // products of plane pairs (pa, pb) with pa + pb < NPL, the small ones first
+        auto mma = [&](const Frags<NPL>& f) {
 #pragma unroll
-            for (int sum = 2; sum >= 0; --sum)
+            for (int sum = NPL - 1; sum >= 0; --sum)
 #pragma unroll
                 for (int pa = 0; pa <= sum; ++pa)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int jn = 0; jn < 2; ++jn)
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[jn][sum - pa], acc[i][jn], 0, 0, 0);
+                            if constexpr (NPL == 2)
+                                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i][pa]),
+                                                                                    __builtin_bit_cast(f16x8, f.b[jn][sum - pa]),
+                                                                                    acc[i][jn], 0, 0, 0);
+                            else
+                                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][pa], f.b[jn][sum - pa], acc[i][jn], 0, 0, 0);
         };
         // LDEPTH register sets rotate: LDEPTH - 1 k blocks are in flight while one is multiplied
-        Frags f[LDEPTH];
+        Frags<NPL> f[LDEPTH];
 #pragma unroll
         for (int d = 0; d < LDEPTH - 1; ++d) load(d, f[d]);
         int j = 0;
@@ -194,10 +233,16 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
             for (int e = 0; e < 16; ++e) part[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + 32 * jn + r] = acc[i][jn][e];
     __syncthreads();
     if (gr >= a.M) return;
+    float inv_a = 1.f, inv_b = 1.f;
+    if constexpr (NPL == 2) {
+        inv_a = a.inv_a_rows ? a.inv_a_rows[gr] : a.inv_a_const;
+        inv_b = a.inv_b[0];
+    }
     auto tile4 = [&](int col) {  // four consecutive columns of this thread's row, summed over the waves
         f32x4 v = *reinterpret_cast<const f32x4*>(lds + (row * LDC + col) * 4);
 #pragma unroll
         for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(lds + w * WAVE_LDS + (row * LDC + col) * 4);
+        if constexpr (NPL == 2) v = (v * inv_a) * inv_b;  // powers of two: exact
         return v;
     };
     if (FWD) {
@@ -222,7 +267,10 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
         *reinterpret_cast<f32x4*>(grow + 3ll * H) = go;
         *reinterpret_cast<f32x4*>(a.c_out + (long long)gr * H + unit0) = c;
         *reinterpret_cast<f32x4*>(a.h_out + (long long)gr * H + unit0) = hh;
-        store_planes4(a.h_planes, a.plane_h, a.rows_h, gr, unit0, hh);
+        if constexpr (NPL == 2)
+            store_planes4h(a.h_planes, a.plane_h, a.rows_h, gr, unit0, hh, H_SCALE);
+        else
+            store_planes4(a.h_planes, a.plane_h, a.rows_h, gr, unit0, hh);
     } else {
         const int c0 = (tid & 3) * 16;
         float* out = a.slabs + ((long long)blockIdx.z * a.M + gr) * a.N + n0 + c0;
@@ -237,10 +285,28 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
 //                  [pl][H/16][4H rows p][16], p = (u / 16) * 64 + g * 16 + u % 16  <-  W_hh[g H + u][k]
 //   wb (backward): B operand of dG W_hh (depth = the 4H gate rows in their own order):
 //                  [pl][4H/16][H rows j][16]  <-  W_hh[q][j]
-// One output element per thread; either image may be null.
+// One output element per thread; either image may be null.  F16: two fp16 planes of W_hh times the power of two
+// its largest magnitude calls for (absmax: GEMM_ABSMAX_PARTS partial maxima of |W_hh|); inv_out[0] = its inverse.
+template <bool F16>
 __global__ __launch_bounds__(256) void lstm_wsplit_kernel(const float* __restrict__ w, int H, unsigned short* __restrict__ wf,
-                                                          unsigned short* __restrict__ wb)
+                                                          unsigned short* __restrict__ wb, const float* __restrict__ absmax,
+                                                          float* __restrict__ inv_out)
 {
+    float scale = 1.f;
+    if constexpr (F16) {
+        __shared__ float sm[4];
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < GEMM_ABSMAX_PARTS / 256; ++q) m = fmaxf(m, absmax[q * 256 + threadIdx.x]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        float inverse;
+        f16x2_scale(m, scale, inverse);
+        if (blockIdx.x == 0 && threadIdx.x == 0) inv_out[0] = inverse;
+    }
     const long long total = 4ll * H * H;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool back = i >= total;
@@ -260,6 +326,13 @@ __global__ __launch_bounds__(256) void lstm_wsplit_kernel(const float* __restric
         const int kk = (int)(i & 15);
         x0 = w[(kb * 16 + kk) * H + j];
     }
+    if constexpr (F16) {
+        const float t = x0 * scale;
+        const _Float16 hi = (_Float16)t, lo = (_Float16)(t - (float)hi);
+        dst[i] = __builtin_bit_cast(unsigned short, hi);
+        dst[total + i] = __builtin_bit_cast(unsigned short, lo);
+        return;
+    }
     const unsigned b0 = __float_as_uint(x0) & 0xffff0000u;
     const float x1 = x0 - __uint_as_float(b0);
     const unsigned b1 = __float_as_uint(x1) & 0xffff0000u;
@@ -267,6 +340,28 @@ __global__ __launch_bounds__(256) void lstm_wsplit_kernel(const float* __restric
     dst[i] = (unsigned short)(b0 >> 16);
     dst[total + i] = (unsigned short)(b1 >> 16);
     dst[2 * total + i] = (unsigned short)(__float_as_uint(x2) >> 16);
+}
+
+// An initial hidden state (rows, cols <= 1024) as the first step's A operand in fp16 planes: one block per row,
+// the row scaled by the power of two its largest magnitude calls for; inv_rows[row] = the inverse.
+__global__ __launch_bounds__(256) void lstm_h0_planes_f16_kernel(const float* __restrict__ x, int rows, int cols,
+                                                                 __bf16* __restrict__ planes, long long plane,
+                                                                 float* __restrict__ inv_rows)
+{
+    __shared__ float sm[4];
+    const int row = blockIdx.x, k0 = threadIdx.x * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k0 < cols) v = *reinterpret_cast<const f32x4*>(x + (long long)row * cols + k0);
+    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float scale, inverse;
+    f16x2_scale(m, scale, inverse);
+    if (threadIdx.x == 0) inv_rows[row] = inverse;
+    if (k0 < cols) store_planes4h(planes, plane, rows, row, k0, v, scale);
 }
 
 // out = a + b (the two bias vectors), and optionally x (rows, cols) -> planes [3][cols/16][rows][16] (an initial
@@ -290,17 +385,43 @@ __global__ __launch_bounds__(256) void lstm_prepare_kernel(const float* __restri
 //   dh = d_hs (if given) + d_extra (if given) + the Z slabs of dG_{t+1} W_hh (if Z > 0)
 //   dc = dc_io (if !first) + d_cT (if first and given) + dh o (1 - tanh(c)^2)
 // writes the pre-activation gradients dG (M, 4H) fp32 and as planes [3][4H/16][M][16], and dc_io = dc f.
+// F16 (H <= 1024): a block takes whole rows (H / 4 threads each), the planes are two fp16 ones of the row times
+// the power of two its largest gate gradient calls for, and inv_rows[row] receives the inverse.
+template <bool F16>
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_t,
                                                             const float* __restrict__ c_prev, const float* __restrict__ d_hs,
                                                             const float* __restrict__ d_extra, const float* __restrict__ slabs,
                                                             int Z, const float* __restrict__ d_cT, int first,
                                                             float* __restrict__ dc_io, float* __restrict__ dG,
-                                                            __bf16* __restrict__ dG_planes, long long plane, int M, int H)
+                                                            __bf16* __restrict__ dG_planes, long long plane, int M, int H,
+                                                            float* __restrict__ inv_rows)
 {
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    __shared__ unsigned rowmax[16];
     const long long MH = (long long)M * H;
-    if (i >= MH) return;
-    const int row = (int)(i / H), u0 = (int)(i % H);
+    long long i;
+    int row, u0, rl = 0;
+    bool active;
+    if constexpr (F16) {
+        const int tpr = H / 4, rpb = 256 / tpr;  // threads per row, rows per block
+        rl = threadIdx.x / tpr;
+        row = blockIdx.x * rpb + rl;
+        u0 = (threadIdx.x % tpr) * 4;
+        active = rl < rpb && row < M;
+        i = (long long)row * H + u0;
+        if (threadIdx.x < 16) rowmax[threadIdx.x] = 0u;
+        __syncthreads();
+    } else {
+        i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+        active = i < MH;
+        row = (int)(i / H);
+        u0 = (int)(i % H);
+    }
+    if (!F16 && !active) return;
+    if (!active) {  // (F16) an idle thread reads element 0 and stores nothing: it still meets the barriers
+        i = 0;
+        row = 0;
+        u0 = 0;
+    }
     // Every load is issued before the first is used.  Optional inputs are read through a stand-in address and
     // discarded (a branch around a load makes the wave wait for everything in flight at the join).
     auto opt = [&](const float* p) {
@@ -338,6 +459,28 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
         df[j] = dcj * cp[j] * gf[j] * (1.f - gf[j]);
         dg[j] = dcj * gi[j] * (1.f - gg[j] * gg[j]);
         dcp[j] = dcj * gf[j];
+    }
+    if constexpr (F16) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(di[j]), fabsf(df[j])), fmaxf(fabsf(dg[j]), fabsf(dO[j]))));
+        if (active) atomicMax(&rowmax[rl], __float_as_uint(m));  // non-negative floats order as their bit patterns
+        __syncthreads();
+        if (!active) return;
+        float scale, inverse;
+        f16x2_scale(__uint_as_float(rowmax[rl]), scale, inverse);
+        if (u0 == 0) inv_rows[row] = inverse;
+        *reinterpret_cast<f32x4*>(dc_io + i) = dcp;
+        float* drow = dG + (long long)row * 4 * H + u0;
+        *reinterpret_cast<f32x4*>(drow) = di;
+        *reinterpret_cast<f32x4*>(drow + (long long)H) = df;
+        *reinterpret_cast<f32x4*>(drow + 2ll * H) = dg;
+        *reinterpret_cast<f32x4*>(drow + 3ll * H) = dO;
+        store_planes4h(dG_planes, plane, M, row, u0, di, scale);
+        store_planes4h(dG_planes, plane, M, row, H + u0, df, scale);
+        store_planes4h(dG_planes, plane, M, row, 2 * H + u0, dg, scale);
+        store_planes4h(dG_planes, plane, M, row, 3 * H + u0, dO, scale);
+        return;
     }
     *reinterpret_cast<f32x4*>(dc_io + i) = dcp;
     float* drow = dG + (long long)row * 4 * H + u0;
@@ -391,6 +534,9 @@ struct FwdWs {
     float* bias;
     unsigned short* wf;
     __bf16* hp[2];
+    float* absmax;  // operand maxima of the large products (GTG_MATRIX_F16X2)
+    float* w_inv;   // fp16 planes: inverse scale of W_hh (one value), inverse row scales of the initial state
+    float* a_inv;
 };
 void fwd_layout(Carve& c, int B, int H, FwdWs* w)
 {
@@ -398,12 +544,18 @@ void fwd_layout(Carve& c, int B, int H, FwdWs* w)
     w->wf = c.take<unsigned short>(12 * (size_t)H * H);
     w->hp[0] = c.take<__bf16>(3 * (size_t)B * H);
     w->hp[1] = c.take<__bf16>(3 * (size_t)B * H);
+    w->absmax = c.take<float>(GEMM_ABSMAX_BYTES / sizeof(float));
+    w->w_inv = c.take<float>(64);
+    w->a_inv = c.take<float>(((size_t)B + 63) / 64 * 64);
 }
 
 struct BwdWs {
     unsigned short* wb;
     __bf16* dgp;
     float *slabs, *dc, *dG, *cs, *gemm_slabs;
+    float* absmax;  // operand maxima of the large products (GTG_MATRIX_F16X2)
+    float* w_inv;   // fp16 planes: inverse scale of W_hh (one value), inverse row scales of a step's gate gradients
+    float* a_inv;
 };
 void bwd_layout(Carve& c, int T, int B, int I, int H, BwdWs* w)
 {
@@ -416,7 +568,13 @@ void bwd_layout(Carve& c, int T, int B, int I, int H, BwdWs* w)
     w->cs = reinterpret_cast<float*>(c.take<char>(colsum_workspace((int64_t)TB, 4 * H)));
     w->gemm_slabs = reinterpret_cast<float*>(c.take<char>(
         max2(gemm_splitk_workspace(4 * H, I, (int)TB, 1), gemm_splitk_workspace(4 * H, H, (int)TB, 1))));
+    w->absmax = c.take<float>(GEMM_ABSMAX_BYTES / sizeof(float));
+    w->w_inv = c.take<float>(64);
+    w->a_inv = c.take<float>(((size_t)B + 63) / 64 * 64);
 }
+
+// the recurrence on fp16 planes: that matrix mode, and rows that fit one block of the kernels that scale them
+inline bool lstm_f16(int H) { return g_matrix_mode == GTG_MATRIX_F16X2 && H <= 1024; }
 
 }  // namespace
 
@@ -454,14 +612,24 @@ int lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* 
     fwd_layout(c, B, H, &w);
     if (ws == nullptr || c.overflow()) return set_error(GTG_ERR_WORKSPACE, "lstm_fwd: workspace too small");
     const long long plane_h = (long long)B * H;
+    const bool f16 = lstm_f16(H);
     {
-        const long long n4 = max2((size_t)4 * H, h0 ? (size_t)B * H : 0) / 4;
-        hipLaunchKernelGGL(lstm_prepare_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b_ih, b_hh, 4 * H, w.bias, h0,
-                           B, H, w.hp[0], plane_h);
+        const float* h0_bf16 = f16 ? nullptr : h0;
+        const long long n4 = max2((size_t)4 * H, h0_bf16 ? (size_t)B * H : 0) / 4;
+        hipLaunchKernelGGL(lstm_prepare_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b_ih, b_hh, 4 * H, w.bias,
+                           h0_bf16, B, H, w.hp[0], plane_h);
         if (int rc = check_launch("lstm_prepare_kernel")) return rc;
         const long long total = 4ll * H * H;
-        hipLaunchKernelGGL(lstm_wsplit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w_hh, H, w.wf,
-                           (unsigned short*)nullptr);
+        const dim3 wgrid((unsigned)((total + 255) / 256));
+        if (f16) {
+            if (int rc = absmax_partials(w_hh, 4ll * H, H, H, w.absmax, s)) return rc;
+            hipLaunchKernelGGL(lstm_wsplit_kernel<true>, wgrid, dim3(256), 0, s, w_hh, H, w.wf, (unsigned short*)nullptr,
+                               w.absmax, w.w_inv);
+            if (h0) hipLaunchKernelGGL(lstm_h0_planes_f16_kernel, dim3(B), dim3(256), 0, s, h0, B, H, w.hp[0], plane_h, w.a_inv);
+        } else {
+            hipLaunchKernelGGL(lstm_wsplit_kernel<false>, wgrid, dim3(256), 0, s, w_hh, H, w.wf, (unsigned short*)nullptr,
+                               (const float*)nullptr, (float*)nullptr);
+        }
         if (int rc = check_launch("lstm_wsplit_kernel")) return rc;
     }
     // the input half of the gates for all steps at once
@@ -470,6 +638,7 @@ int lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* 
     g.B = w_ih; g.ldb = I; g.b_kc = true;
     g.C = gates; g.ldc = 4 * H; g.M = T * B; g.N = 4 * H; g.K = I;
     g.bias = w.bias;
+    g.absmax_ws = w.absmax;
     if (int rc = gemm(g, s)) return rc;
 
     StepArgs a{};
@@ -478,6 +647,7 @@ int lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* 
     a.planeA = plane_h; a.rowsA = B;
     a.M = B; a.N = 4 * H; a.H = H;
     a.plane_h = plane_h; a.rows_h = B;
+    a.inv_b = w.w_inv; a.inv_a_const = H_INV;
     const dim3 grid(H / 16, (B + LT - 1) / LT, 1);
     for (int st = 0; st < T; ++st) {
         const int t = reverse ? T - 1 - st : st;
@@ -489,7 +659,11 @@ int lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         a.c_prev = st == 0 ? c0 : cs + (long long)tp * B * H;
         a.h_out = hs + (long long)t * B * H;
         a.c_out = cs + (long long)t * B * H;
-        hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(256), 0, s, a);
+        a.inv_a_rows = (st == 0 && h0 != nullptr) ? w.a_inv : nullptr;  // a given initial state has row scales of its own
+        if (f16)
+            hipLaunchKernelGGL((lstm_step_kernel<true, 2>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((lstm_step_kernel<true, 3>), grid, dim3(256), 0, s, a);
     }
     return check_launch("lstm_step_kernel<fwd>");
 }
@@ -508,9 +682,19 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
     bwd_layout(c, T, B, I, H, &w);
     if (ws == nullptr || c.overflow()) return set_error(GTG_ERR_WORKSPACE, "lstm_bwd: workspace too small");
     const long long BH = (long long)B * H, total = 4ll * H * H;
-    hipLaunchKernelGGL(lstm_wsplit_kernel, dim3((unsigned)((2 * total + 255) / 256)), dim3(256), 0, s, w_hh, H,
-                       (unsigned short*)nullptr, w.wb);
-    if (int rc = check_launch("lstm_wsplit_kernel")) return rc;
+    const bool f16 = lstm_f16(H);
+    {
+        const dim3 wgrid((unsigned)((2 * total + 255) / 256));
+        if (f16) {
+            if (int rc = absmax_partials(w_hh, 4ll * H, H, H, w.absmax, s)) return rc;
+            hipLaunchKernelGGL(lstm_wsplit_kernel<true>, wgrid, dim3(256), 0, s, w_hh, H, (unsigned short*)nullptr, w.wb,
+                               w.absmax, w.w_inv);
+        } else {
+            hipLaunchKernelGGL(lstm_wsplit_kernel<false>, wgrid, dim3(256), 0, s, w_hh, H, (unsigned short*)nullptr, w.wb,
+                               (const float*)nullptr, (float*)nullptr);
+        }
+        if (int rc = check_launch("lstm_wsplit_kernel")) return rc;
+    }
 
     const int Z = bwd_slabs(B, H);
     StepArgs a{};
@@ -519,16 +703,28 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
     a.M = B; a.N = H; a.H = H;
     a.kb_per_split = 4 * H / 16 / Z;
     a.slabs = w.slabs;
+    a.inv_b = w.w_inv; a.inv_a_rows = w.a_inv; a.inv_a_const = 1.f;
     const dim3 grid((H + LT - 1) / LT, (B + LT - 1) / LT, Z);
     const unsigned cell_blocks = (unsigned)((BH / 4 + 255) / 256);
+    const int rows_per_block = 256 / (H / 4 > 256 ? 256 : H / 4);  // F16: whole rows per block
+    const unsigned cell_blocks_f16 = (unsigned)((B + rows_per_block - 1) / rows_per_block);
     for (int st = T - 1; st >= 0; --st) {
         const int t = reverse ? T - 1 - st : st;
         const int tp = reverse ? t + 1 : t - 1;
         const bool first = st == T - 1;
-        hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cell_blocks), dim3(256), 0, s, gates + (long long)t * 4 * BH, cs + t * BH,
-                           st == 0 ? c0 : cs + tp * BH, d_hs ? d_hs + t * BH : nullptr, first ? d_hT : nullptr, w.slabs,
-                           first ? 0 : Z, d_cT, first ? 1 : 0, w.dc, w.dG + (long long)t * 4 * BH, w.dgp, 4ll * BH, B, H);
-        if (st > 0 || dh0 != nullptr) hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(256), 0, s, a);
+        if (f16) {
+            hipLaunchKernelGGL(lstm_cell_bwd_kernel<true>, dim3(cell_blocks_f16), dim3(256), 0, s, gates + (long long)t * 4 * BH,
+                               cs + t * BH, st == 0 ? c0 : cs + tp * BH, d_hs ? d_hs + t * BH : nullptr, first ? d_hT : nullptr,
+                               w.slabs, first ? 0 : Z, d_cT, first ? 1 : 0, w.dc, w.dG + (long long)t * 4 * BH, w.dgp, 4ll * BH, B,
+                               H, w.a_inv);
+            if (st > 0 || dh0 != nullptr) hipLaunchKernelGGL((lstm_step_kernel<false, 2>), grid, dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(lstm_cell_bwd_kernel<false>, dim3(cell_blocks), dim3(256), 0, s, gates + (long long)t * 4 * BH,
+                               cs + t * BH, st == 0 ? c0 : cs + tp * BH, d_hs ? d_hs + t * BH : nullptr, first ? d_hT : nullptr,
+                               w.slabs, first ? 0 : Z, d_cT, first ? 1 : 0, w.dc, w.dG + (long long)t * 4 * BH, w.dgp, 4ll * BH, B,
+                               H, (float*)nullptr);
+            if (st > 0 || dh0 != nullptr) hipLaunchKernelGGL((lstm_step_kernel<false, 3>), grid, dim3(256), 0, s, a);
+        }
     }
     if (int rc = check_launch("lstm backward recurrence")) return rc;
     if (dh0) {
@@ -548,6 +744,7 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
     g.B = x; g.ldb = I; g.b_kc = false;
     g.C = dw_ih; g.ldc = I; g.M = 4 * H; g.N = I; g.K = TB;
     g.splits = gemm_pick_splits(4 * H, I, TB, 1); g.slabs = w.gemm_slabs;
+    g.absmax_ws = w.absmax;
     if (int rc = gemm(g, s)) return rc;
     // dW_hh = sum over steps of dG_t^T h_(previous step): a contiguous run of steps in both buffers, plus the
     // first step against h0
@@ -557,6 +754,8 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         g.B = hs + (reverse ? BH : 0); g.ldb = H; g.b_kc = false;
         g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = (T - 1) * B;
         g.splits = gemm_pick_splits(4 * H, H, (T - 1) * B, 1); g.slabs = w.gemm_slabs;
+        g.absmax_ws = w.absmax;
+        g.b_bound = 1.f;  // hidden states
         if (int rc = gemm(g, s)) return rc;
     } else if (int rc = clear_i32(reinterpret_cast<int32_t*>(dw_hh), total, s)) {  // one step and no h0 term yet: zero
         return rc;
@@ -567,6 +766,7 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         g.B = h0; g.ldb = H; g.b_kc = false;
         g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = B;
         g.epi = EPI_ACCUM;
+        g.absmax_ws = w.absmax;
         if (int rc = gemm(g, s)) return rc;
     }
     if (dx) {
@@ -574,6 +774,7 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         g.A = w.dG; g.lda = 4 * H; g.a_kc = true;
         g.B = w_ih; g.ldb = I; g.b_kc = false;
         g.C = dx; g.ldc = I; g.M = TB; g.N = I; g.K = 4 * H;
+        g.absmax_ws = w.absmax;
         if (int rc = gemm(g, s)) return rc;
     }
     return GTG_OK;

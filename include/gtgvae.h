@@ -47,6 +47,17 @@ extern "C" {
  *                      v_mfma_f32_32x32x16_bf16 with fp32 accumulation: the error
  *                      against float64 equals the fp32 pipe's (about 1e-6 of max|C|),
  *                      at 1.5x its speed.  Inf operands give NaN (inf - inf in the split).
+ *   GTG_MATRIX_F16X2   every operand is scaled by a power of two that puts its largest
+ *                      magnitude below 2^14 (found by a pass over the operand right before
+ *                      the product) and split into two fp16 pieces, each rounded to nearest
+ *                      (11 + 11 significant bits and the sign of the remainder); the three
+ *                      piece products of weight >= 2^-11 run on v_mfma_f32_32x32x16_f16 with
+ *                      fp32 accumulation and the result is scaled back: the same error
+ *                      against float64 as GTG_MATRIX_BF16X3 with half its matrix
+ *                      instructions.  Values below 2^-28 of an operand's largest lose relative
+ *                      precision (not absolute); Inf operands give NaN.  Products whose
+ *                      operands arrive pre-split as bf16 planes, the batched forms and the LSTM
+ *                      recurrence run the GTG_MATRIX_BF16X3 arithmetic in this mode.
  *   GTG_MATRIX_BF16    operands rounded to bf16 (round to nearest even), one product:
  *                      about 3e-3 of max|C|; for loss tolerances of 1e-3. */
 /* The encoder entry points launch one grid row per graph: at most this many graphs per call. */
@@ -54,6 +65,7 @@ extern "C" {
 
 #define GTG_MATRIX_F32 0
 #define GTG_MATRIX_BF16 1
+#define GTG_MATRIX_F16X2 2
 #define GTG_MATRIX_BF16X3 3
 
 int gtg_version(void);

@@ -134,7 +134,8 @@ def test_rows_on_device_mask_epilogue():
     assert bool((got[rows:] == 0).all())
 
 
-# ---- matrix pipes: the three-plane bf16 split must be as accurate as the fp32 pipe; plain bf16 is coarse
+# ---- matrix pipes: the three-plane bf16 split and the scaled two-plane fp16 split must be as accurate as the
+# fp32 pipe; plain bf16 is coarse
 MODE_SHAPES = [  # all large enough for the 128x128 configuration the modes apply to
     ("NT", 8192, 512, 1024), ("NN", 4096, 1024, 512), ("TN", 2048, 2048, 4096),
     ("NT", 5000, 700, 333), ("NN", 5001, 701, 77), ("TN", 2100, 1801, 1003),
@@ -157,17 +158,19 @@ def test_bf16x3_pipe_is_as_accurate_as_fp32_pipe(layout, M, N, K):
     want = (a if a_kc else a.t()) @ (b.t() if b_kc else b)
     scale = ((a.abs() if a_kc else a.abs().t()) @ (b.abs().t() if b_kc else b.abs()))  # sum |a||b| per element
     err = {}
-    for mode in ("f32", "bf16x3", "bf16"):
-        got = Fn.gemm(A, B, a_kc, b_kc, split_k=False, matrix_mode=mode)
+    for mode in ("f32", "bf16x3", "f16x2", "bf16"):
+        got = Fn.gemm(A, B, a_kc, b_kc, matrix_mode=mode)
         err[mode] = ((got.double() - want).abs() / scale).max().item()
     # errors are relative to sum_k |a||b|, the scale fp32 rounding acts on (the fp32 pipe itself: a few 1e-6 at K ~ 1000)
     assert err["f32"] < 2e-5, err
     assert err["bf16x3"] < 2.0 * err["f32"] + 2e-7, err
+    assert err["f16x2"] < 2.0 * err["f32"] + 2e-7, err
     assert 1e-5 < err["bf16"] < 2e-2, err          # really the coarse pipe, and sane
-    print("\n%s M=%d N=%d K=%d  f32 %.2e  bf16x3 %.2e  bf16 %.2e" % (layout, M, N, K, err["f32"], err["bf16x3"], err["bf16"]))
+    print("\n%s M=%d N=%d K=%d  f32 %.2e  bf16x3 %.2e  f16x2 %.2e  bf16 %.2e" % (layout, M, N, K, err["f32"], err["bf16x3"], err["f16x2"], err["bf16"]))
 
 
-def test_bf16x3_pipe_epilogues_ragged_rows_and_split_k():
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_bf16x3_pipe_epilogues_ragged_rows_and_split_k(mode):
     from gtg_vae_amd import functional as Fn
 
     torch.manual_seed(5)
@@ -176,24 +179,47 @@ def test_bf16x3_pipe_epilogues_ragged_rows_and_split_k():
     B = torch.randn(K, N, device="cuda")
     aux = torch.randn(M, N, device="cuda")
     rd = torch.tensor([rows], dtype=torch.int32, device="cuda")
-    got = Fn.gemm_rows(A, B, True, False, rows_dev=rd, epilogue=3, aux=aux, matrix_mode="bf16x3")
+    got = Fn.gemm_rows(A, B, True, False, rows_dev=rd, epilogue=3, aux=aux, matrix_mode=mode)
     want = torch.where(aux[:rows] > 0, A[:rows].double() @ B.double(), torch.zeros((), dtype=torch.float64, device="cuda"))
     assert (got[:rows].double() - want).abs().max().item() < _tol(K) * 40
     assert bool((got[rows:] == 0).all())
     # tail split (652 tiles) through the bf16 pipe, bitwise reproducible
     A2 = torch.randn(M, 1024, device="cuda")
     B2 = torch.randn(512, 1024, device="cuda")
-    o1 = Fn.gemm_rows(A2, B2, True, True, rows_dev=rd, matrix_mode="bf16x3")
-    o2 = Fn.gemm_rows(A2, B2, True, True, rows_dev=rd, matrix_mode="bf16x3")
+    o1 = Fn.gemm_rows(A2, B2, True, True, rows_dev=rd, matrix_mode=mode)
+    o2 = Fn.gemm_rows(A2, B2, True, True, rows_dev=rd, matrix_mode=mode)
     assert torch.equal(o1, o2)
     assert (o1[:rows].double() - A2[:rows].double() @ B2.double().t()).abs().max().item() < _tol(1024) * 40
     # split-K weight gradient
     X = torch.randn(32768, 512, device="cuda")
     Y = torch.randn(32768, 1024, device="cuda")
-    g1 = Fn.gemm(X, Y, False, False, matrix_mode="bf16x3")
-    g2 = Fn.gemm(X, Y, False, False, matrix_mode="bf16x3")
+    g1 = Fn.gemm(X, Y, False, False, matrix_mode=mode)
+    g2 = Fn.gemm(X, Y, False, False, matrix_mode=mode)
     assert torch.equal(g1, g2)
     assert (g1.double() - X.double().t() @ Y.double()).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("sa,sb", [(1e-30, 1e20), (3e25, 1e-12), (1.0, 0.0), (7e-39, 1.0)])
+def test_f16x2_pipe_rescales_tiny_and_huge_operands(sa, sb):
+    """The two-plane fp16 split scales every operand by a power of two found from its largest magnitude: results
+    for operands far outside fp16's range (and an all-zero one, and one of fp32 subnormals) keep the fp32-level
+    error relative to sum |a||b|."""
+    from gtg_vae_amd import functional as Fn
+
+    torch.manual_seed(11)
+    M, N, K = 2048, 1536, 320
+    A = torch.randn(M, K, device="cuda") * sa
+    B = torch.randn(N, K, device="cuda") * sb
+    got = Fn.gemm(A, B, True, True, matrix_mode="f16x2")
+    want = A.double() @ B.double().t()
+    scale = (A.double().abs() @ B.double().abs().t()).clamp_min(1e-300)
+    assert torch.isfinite(got).all()
+    if sb == 0.0:
+        assert float(got.abs().max()) == 0.0
+    elif sa < 1e-37:   # subnormal inputs: the operand itself carries only a few bits
+        assert ((got.double() - want).abs() / scale).max().item() < 1e-2
+    else:
+        assert ((got.double() - want).abs() / scale).max().item() < 2e-6
 
 
 def _unblock(p):

@@ -79,7 +79,7 @@ def test_joint_forward_matches_composition_of_reference_pieces():
     assert abs(acc - text_acc) < 1e-6
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("name,B,N,d,hid", [("A", 64, 10, 32, 512), ("B", 256, 32, 256, 512), ("C", 512, 64, 512, 512)])
 def test_named_config_training_step_matches_oracle(name, B, N, d, hid, mode):
     """Reference defaults (A), the mid-size configuration (B) and the headline configuration at full size

@@ -31,8 +31,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("T,B,I,H,reverse,init", CASES)
-def test_lstm_forward_and_backward_match_oracle(T, B, I, H, reverse, init):
+def test_lstm_forward_and_backward_match_oracle(T, B, I, H, reverse, init, mode):
     from gtg_vae_amd import functional as Fn
     from oracle import textvae_oracle as TO
 
@@ -54,7 +55,7 @@ def test_lstm_forward_and_backward_match_oracle(T, B, I, H, reverse, init):
 
     cu = [t.clone().cuda().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
     cu_init = [t.clone().cuda().requires_grad_(True) for t in (h0, c0)] if init else [None, None]
-    hs, ghT, gcT = Fn.lstm(cu[0], cu[1], cu[2], cu[3], cu[4], cu_init[0], cu_init[1], reverse, "bf16x3")
+    hs, ghT, gcT = Fn.lstm(cu[0], cu[1], cu[2], cu[3], cu[4], cu_init[0], cu_init[1], reverse, mode)
     assert _relerr(hs, out) < 1e-5 and _relerr(ghT, hT) < 1e-5 and _relerr(gcT, cT) < 1e-5
     ((hs * d_hs.cuda()).sum() + (ghT * d_hT.cuda()).sum() + (gcT * d_cT.cuda()).sum()).backward()
     names = ("x", "w_ih", "w_hh", "b_ih", "b_hh")

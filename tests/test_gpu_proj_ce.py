@@ -51,7 +51,7 @@ def _close(got, want, rtol):
     return np.abs(got - want).max() <= rtol * scale
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("R,K,V,pad_every", [
     (37, 24, 50, 3),        # ragged everything, scalar row tails
     (300, 64, 1000, 4),
