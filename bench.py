@@ -174,6 +174,8 @@ def joint_bench(dev, steps=8):
     dt = (time.perf_counter() - t0) / steps
     return {"workload": "configs[4] on one GPU: joint graph+text step, batch 256, N=32, d=256, T<=40, vocab 30522; "
                         "HIP graph half + HIP LSTM recurrences + HIP vocabulary projection/cross-entropy + flat fused Adam",
+            "matrix_mode": "f16x2 (the library default: fp32 operands and results, two scaled fp16 planes and three "
+                           "products per multiply-add in the large products and the LSTM recurrence)",
             "ms_per_step": dt * 1e3, "graphs_per_s": B / dt, "parameters": tr.numel}
 
 

@@ -488,7 +488,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC, 
 constexpr int gemm_smem_floats()
 {
     constexpr int GT = 64 * WAVES_M * WAVES_N;
-    constexpr int KS = (PREC == 3 || PREC == 2) ? 16 : BK;
+    constexpr int KS = (PREC == 3) ? 16 : BK;
     constexpr int TPL = (PREC == 0 || PREC == 4) ? 1 : PREC;
     using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, TPL, KS>>::type;
     using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, TPL, KS>>::type;
@@ -497,8 +497,10 @@ constexpr int gemm_smem_floats()
                                      : KG * 2 * (TA::SIZE + TB::SIZE),
                   EPI = KG * WAVES_M * WAVES_N * WTM * (WTN + 4);
     // + 4: the tail split's "last arriver" word lives behind the buffers, in the same array (a second __shared__
-    // object beside an array that LDS-DMA fills makes the compiler drain all loads before every LDS read)
-    return (MAIN > EPI ? MAIN : EPI) + 4;
+    // object beside an array that LDS-DMA fills makes the compiler drain all loads before every LDS read).  The
+    // two-plane fp16 tiles (k step 32) fill exactly half a CU's LDS with the 128x128 tile's four buffers, and the
+    // word sits in the unused pad that ends the last one, so that two blocks still share a CU.
+    return (MAIN > EPI ? MAIN : EPI) + ((PREC == 2 && MAIN >= EPI + 4) ? 0 : 4);
 }
 
 // One block's share of a GEMM launch: block `block_x` of `grid_x`, LDS at `smem` (gemm_smem_floats() floats).
@@ -509,7 +511,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
     constexpr int GT = 64 * WAVES_M * WAVES_N;  // threads of one wave group
     constexpr int GW = WAVES_M * WAVES_N;
     // k extent of one pipeline step: the three-plane tiles take 16 so that two blocks still fit a CU's LDS
-    constexpr int KS = (PREC == 3 || PREC == 4 || PREC == 2) ? 16 : BK;
+    constexpr int KS = (PREC == 3 || PREC == 4) ? 16 : BK;
     constexpr int TPL = (PREC == 0 || PREC == 4) ? 1 : PREC;  // planes of the register-staged bf16 tiles
     using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, TPL, KS>>::type;
     using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, TPL, KS>>::type;

@@ -319,7 +319,9 @@ int gtg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * C[M,N] = epilogue(op(A) op(B)); a_kc: A(m,k) at A[m*lda+k] else A[k*lda+m];
  * b_kc: B(k,n) at B[n*ldb+k] else B[k*ldb+n].  epilogue: 0 store(+bias),
  * 1 relu(+bias), 2 sigmoid(+bias), 3 mask by aux>0, 4 accumulate into C.
- * slabs (optional) enables ordered split-K for short-and-wide shapes. */
+ * slabs (optional, gtg_gemm_splitk_workspace_bytes() device bytes) enables ordered
+ * split-K for short-and-wide shapes and holds the operand maxima GTG_MATRIX_F16X2
+ * needs; without it that mode runs the GTG_MATRIX_BF16X3 arithmetic. */
 int gtg_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
                  int b_kc, const float* bias, int epilogue, const float* aux, int ldaux, void* slabs,
                  size_t slab_bytes, int matrix_mode, void* stream);
