@@ -59,7 +59,7 @@ class GraphVAETrainer:
         self.f, self.d, self.hid, self.n = input_dim, latent_dim, mlp_hid_dim, nmax
         self.m = nmax * (nmax + 1) // 2
         self.lr, self.betas, self.eps = lr, betas, eps
-        # matrix pipe of the large encoder GEMMs: "f32" | "bf16x3" (fp32-accurate, the default) | "bf16"
+        # matrix pipe of the large GEMMs: "f32" | "f16x2" (the default) | "bf16x3" (both fp32-accurate) | "bf16"
         self.matrix_mode = _lib.matrix_mode(matrix_mode)
 
         # ---- flat parameter / gradient / moment buffers -----------------------

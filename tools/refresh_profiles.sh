@@ -30,4 +30,5 @@ cp $out/jprof/*/*_kernel_stats.csv $out/${tag}_joint_kernel_stats.csv
 timeout -k 10 200 python3 $repo/tools/lstm_bench.py > $out/${tag}_lstm_bench.txt 2>> $out/bench.err
 timeout -k 10 200 python3 $repo/tools/planes_bench.py > $out/${tag}_planes_bench.txt 2>> $out/bench.err
 timeout -k 10 200 python3 $repo/tools/proj_ce_bench.py > $out/${tag}_proj_ce_bench.json 2>> $out/bench.err
+timeout -k 10 300 python3 $repo/tools/f16x2_bench.py > $out/${tag}_f16x2_bench.txt 2>> $out/bench.err
 echo refreshed
