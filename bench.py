@@ -34,7 +34,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak
 # bf16 MFMA products issued per fp32-equivalent multiply-add in each matrix mode
-MODE_PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16": 1}
+MODE_PRODUCTS = {"f32": 1, "bf16x3": 6, "f16x2": 3, "bf16": 1}
 PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E peak
 
 
@@ -227,7 +227,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mst", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sub-records of configurations A, B and the joint step")
-    ap.add_argument("--matrix", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
+    ap.add_argument("--matrix", choices=["f32", "bf16x3", "f16x2", "bf16"], default="bf16x3",
                     help="matrix pipe of the large encoder GEMMs: fp32 MFMA; the exact three-way bf16 split on the bf16 "
                          "MFMA (fp32-level error, default); plain bf16 operands (loss tolerance 1e-3)")
     ap.add_argument("--no-alt", action="store_true", help="skip the short extra runs in the other matrix modes")
@@ -360,10 +360,12 @@ def main():
             # MFMA products actually issued (six per multiply-add for the three-way split)
             on_bf16 = args.matrix != "f32" and name.startswith("gemm128")
             peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_F32_MFMA_TFLOPS
-            issued = ach * (MODE_PRODUCTS[args.matrix] if on_bf16 else 1)
+            # (operands that arrive as pre-split bf16 planes run the six products of the three-way split in f16x2 too)
+            products = 6 if (args.matrix == "f16x2" and "_planes" in name) else MODE_PRODUCTS[args.matrix]
+            issued = ach * (products if on_bf16 else 1)
             roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s",
                     "frac": issued / peak, "traffic": traffic, "traffic_source": PMC_SOURCE_NOTE, "kernel": name,
-                    "pipe": ("v_mfma_f32_32x32x16_bf16, %d products per fp32 multiply-add" % MODE_PRODUCTS[args.matrix])
+                    "pipe": ("v_mfma_f32_32x32x16_bf16 / _f16, %d products per fp32 multiply-add" % products)
                             if on_bf16 else "v_mfma_f32_32x32x2_f32",
                     "fp32_equivalent_tflops": ach,
                     # the same launch priced as what it computes (fp32 multiply-adds) against the fp32 matrix peak
@@ -394,6 +396,10 @@ def main():
                                                  "exactly into three bf16 pieces and sum six piece products on the bf16 MFMA "
                                                  "with fp32 accumulation (error vs float64 equal to the fp32 MFMA's; the "
                                                  "parity tests run at the fp32 tolerances in this mode)",
+                                       "f16x2": "fp32 operands and results; the encoder's forward product scales every "
+                                                "operand by a power of two, splits it into two fp16 pieces and sums three "
+                                                "piece products on the fp16 MFMA; its backward product runs on pre-split "
+                                                "bf16 planes as in bf16x3 (error vs float64 equal to the fp32 MFMA's)",
                                        "bf16": "large encoder GEMMs on bf16-rounded operands, fp32 accumulation "
                                                "(loss tolerance 1e-3)"}[args.matrix]},
             "step_executed": {"gemm_gflop_per_step": gemm_flops / 1e9,

@@ -397,6 +397,7 @@ struct EncCFwdWs {
     float *t2c, *tail;
     int32_t* tail_cnt;
     size_t tail_cnt_count;
+    float* absmax;
 };
 
 static void enc_cfwd_layout(Carver& c, int64_t B, int n, int d, EncCFwdWs* w)
@@ -407,6 +408,7 @@ static void enc_cfwd_layout(Carver& c, int64_t B, int n, int d, EncCFwdWs* w)
     w->tail = reinterpret_cast<float*>(c.take<char>(tb));
     w->tail_cnt = reinterpret_cast<int32_t*>(c.take<char>(cb));
     w->tail_cnt_count = cb / sizeof(int32_t);
+    w->absmax = reinterpret_cast<float*>(c.take<char>(GEMM_ABSMAX_BYTES));
 }
 
 size_t gtg_encoder_compact_fwd_workspace_bytes(int64_t num_graphs, int n, int d)
@@ -441,12 +443,15 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const floa
 
     GTG_TRY(graph_meta(extents, adj, B, n, meta, adjc, w.tail_cnt, (int)w.tail_cnt_count, s));
     GemmDesc g;
+    bool conv1_maxima = false;
     // H1c = relu(adjc * W1^T + b1) over the R + n stored rows: a graph's compact adjacency rows are zero past
     // its n_b columns, so one product with K = n serves every graph, and the unit rows appended to adjc give
     // the prototype rows relu(W1^T + b1) in the same launch.  A row of adjc holds deg + 1 nonzeros: the product
     // runs as a sparse row kernel bound by the store of H1c (dense GEMM when 2d is not a multiple of 4).
     if ((H & 3) == 0) {
-        GTG_TRY(conv1_sparse(adjc, n, W1, b1, H, all_rows, rows, h1c, s));
+        // (in the two-plane fp16 mode the kernel also leaves the maxima of H1c and W2 that the next product scales by)
+        conv1_maxima = matrix_mode == GTG_MATRIX_F16X2;
+        GTG_TRY(conv1_sparse(adjc, n, W1, b1, H, all_rows, rows, h1c, conv1_maxima ? w.absmax : nullptr, W2, (long long)d * H, s));
     } else {
         g.A = adjc; g.lda = n; g.a_kc = true;
         g.B = W1; g.ldb = n; g.b_kc = true;
@@ -461,6 +466,8 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const floa
     g.A = h1c; g.lda = H; g.B = W2; g.ldb = H; g.C = w.t2c; g.ldc = d;
     g.M = rows; g.N = d; g.K = H; g.m_dev = all_rows;
     g.tail_ws = w.tail; g.tail_counters = w.tail_cnt;
+    g.absmax_ws = w.absmax;
+    g.absmax_ready = conv1_maxima;
     GTG_TRY(gemm(g, s));
     // pooled[b] = max( max_{i<n_b}(A_b * T2c[b] + b2), max of the prototype rows from n_b on (+ b2) ): the
     // epilogue reads those rows of T2c itself.  Sparse per-graph kernel when d is a multiple of 4 (the adjacency
@@ -480,6 +487,7 @@ struct EncCBwdWs {
     float *dT2c, *dZ1c, *pg, *cs, *slabs, *tail, *dw2;
     float* proto_rows;   // plane path: the prototype rows' gradient as fp32
     void* w2t_planes;    // plane path: W2^T as k-blocked bf16 planes
+    float *inv_rows, *inv_w;  // fp16 planes: inverse row scales of dT2c (rows) and of W2^T (H)
     int32_t* tail_cnt;
     size_t tail_cnt_count;
 };
@@ -492,6 +500,8 @@ static void enc_cbwd_layout(Carver& c, int64_t B, int n, int d, EncCBwdWs* w)
     w->dT2c = reinterpret_cast<float*>(c.take<char>(rows * d * 6));
     w->proto_rows = c.take<float>((size_t)n * d);
     w->w2t_planes = c.take<char>((size_t)d * H * 6);
+    w->inv_rows = c.take<float>(rows);
+    w->inv_w = c.take<float>((size_t)H);
     w->dZ1c = c.take<float>(rows * H);
     w->pg = reinterpret_cast<float*>(c.take<char>(proto_grad_workspace(n, d)));
     w->cs = reinterpret_cast<float*>(c.take<char>(max2(max2(colsum_workspace(B, d), colsum_workspace((int64_t)rows, H)),
@@ -540,9 +550,11 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     const bool planes = matrix_mode_split(matrix_mode) && pool_bwd_gather_planes_applies(n, d) && dw2_sparse_applies(B, n, d, H) &&
                         (long long)((rows + 127) / 128) * ((H + 127) / 128) >= 192;
     // dT2c: real rows from the max-pool routing, prototype rows from the graphs whose maximum they won
+    const bool f16 = planes && matrix_mode == GTG_MATRIX_F16X2;  // two fp16 planes, three products
     if (planes) {
         GTG_TRY(pool_bwd_gather_planes(adj, dpooled, argmax, meta, B, n, d, rows, w.dT2c, w.proto_rows, w.pg, w.tail_cnt,
-                                       (int)w.tail_cnt_count, W2, d, H, H, w.w2t_planes, s));
+                                       (int)w.tail_cnt_count, W2, d, H, H, w.w2t_planes, f16 ? w.inv_rows : nullptr,
+                                       f16 ? w.inv_w : nullptr, s));
     } else {
         GTG_TRY(pool_bwd_gather_compact(adj, dpooled, argmax, meta, B, n, d, w.dT2c, w.pg, w.tail_cnt, (int)w.tail_cnt_count, s));
     }
@@ -564,6 +576,7 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
         g.planes = true;
         g.A = w.dT2c; g.lda = rows; g.planeA = (long long)d * rows;
         g.B = reinterpret_cast<const float*>(w.w2t_planes); g.ldb = H; g.planeB = (long long)d * H;
+        if (f16) { g.planes_inv_a = w.inv_rows; g.planes_inv_b = w.inv_w; }
     } else {
         g.A = w.dT2c; g.lda = d; g.a_kc = true;
         g.B = W2; g.ldb = H; g.b_kc = false;

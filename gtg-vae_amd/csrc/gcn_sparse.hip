@@ -35,13 +35,21 @@ constexpr int C1_LD = C1_COLS + 4; // LDS row stride of the transposed weight sl
 constexpr int C1_UNROLL = 4;       // adjacency rows in flight per wave
 
 // grid = slabs * chunks; block b: column slab b % slabs, row chunk b / slabs.
+// With `absmax` (2 x GEMM_ABSMAX_PARTS floats): the partial maxima the two-plane fp16 GEMM that consumes h1c wants
+// of its operands -- the block's largest stored activation in slot b, the largest magnitude of its share of the
+// `w_next_count` weights at w_next in slot GEMM_ABSMAX_PARTS + b, zeros in the slots no block owns -- so that
+// product needs no pass of its own over them.  The grid has at most GEMM_ABSMAX_PARTS blocks.
 __global__ __launch_bounds__(C1_THREADS) void conv1_sparse_kernel(const float* __restrict__ adjc, int n,
                                                                   const float* __restrict__ W1,
                                                                   const float* __restrict__ b1, int H,
                                                                   const int* __restrict__ rows_dev, int rows_max,
-                                                                  int slabs, float* __restrict__ h1c)
+                                                                  int slabs, float* __restrict__ h1c,
+                                                                  float* __restrict__ absmax,
+                                                                  const float* __restrict__ w_next, long long w_next_count)
 {
     __shared__ __attribute__((aligned(16))) float Wt[64 * C1_LD];  // Wt[k][c] = W1[c0 + c][k]
+    __shared__ float smax[2][C1_THREADS / 64];
+    float amax = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slab = blockIdx.x % slabs, chunk = blockIdx.x / slabs, chunks = gridDim.x / slabs;
     const int c0 = slab * C1_COLS;
@@ -108,8 +116,36 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_sparse_kernel(const float* _
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = fmaxf(acc[q], 0.f);
-            if (col_ok) *reinterpret_cast<f32x4*>(h1c + (long long)r * H + col) = acc;
+            if (col_ok) {
+                *reinterpret_cast<f32x4*>(h1c + (long long)r * H + col) = acc;
+                amax = fmaxf(amax, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+            }
         }
+    }
+    if (absmax == nullptr) return;  // kernel argument: uniform
+    float wmax = 0.f;
+    {
+        const long long per = (w_next_count + gridDim.x - 1) / gridDim.x;
+        const long long e0 = (long long)blockIdx.x * per, e1 = min(w_next_count, e0 + per);
+        for (long long e = e0 + tid; e < e1; e += C1_THREADS) wmax = fmaxf(wmax, fabsf(w_next[e]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, o));
+        wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    }
+    if (lane == 0) {
+        smax[0][wave] = amax;
+        smax[1][wave] = wmax;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        float m = 0.f;
+#pragma unroll
+        for (int w = 0; w < C1_THREADS / 64; ++w) m = fmaxf(m, smax[tid][w]);
+        float* out = absmax + tid * GEMM_ABSMAX_PARTS;
+        out[blockIdx.x] = m;
+        for (int sl = blockIdx.x + gridDim.x; sl < GEMM_ABSMAX_PARTS; sl += gridDim.x) out[sl] = 0.f;
     }
 }
 
@@ -414,15 +450,16 @@ __global__ __launch_bounds__(256) void dw2_reduce_kernel(const float* __restrict
 }  // namespace
 
 int conv1_sparse(const float* adjc, int n, const float* W1, const float* b1, int H, const int* rows_dev, int rows_max,
-                 float* h1c, hipStream_t s)
+                 float* h1c, float* absmax, const float* w_next, long long w_next_count, hipStream_t s)
 {
     if (n < 1 || n > 64 || (H & 3) != 0) return set_error(GTG_ERR_INVALID, "conv1_sparse: n in [1, 64], H a multiple of 4");
     const int slabs = (H + C1_COLS - 1) / C1_COLS;
     int chunks = 512 / slabs;  // two blocks of 512 threads per CU
     if (chunks < 1) chunks = 1;
     ProfScope prof(s, "conv1_sparse", rows_max, H, n);
+    if (slabs * chunks > GEMM_ABSMAX_PARTS) absmax = nullptr;  // (never: at most 512 blocks)
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(slabs * chunks), dim3(C1_THREADS), 0, s, adjc, n, W1, b1, H, rows_dev,
-                       rows_max, slabs, h1c);
+                       rows_max, slabs, h1c, absmax, w_next, w_next_count);
     return check_launch("conv1_sparse_kernel");
 }
 

@@ -59,6 +59,9 @@ struct KArgs {
     // PREC 2: ABSMAX_PARTS partial maxima of |A| followed by as many of |B| (absmax_pair_kernel), from which every
     // block derives the two power-of-two operand scales
     const float* absmax;
+    // PREC 5 (fp16 plane images [2][K/16][rows][16]): inverse row scales of A (M) and of B (N)
+    const float* inv_a_rows;
+    const float* inv_b_rows;
 };
 
 constexpr int ABSMAX_PARTS = GEMM_ABSMAX_PARTS;
@@ -451,13 +454,13 @@ struct TileB {
 // bytes at row r, half h, so a wave's fragment read is one contiguous kilobyte, conflict-free).  The stage is
 // filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = 32 rows per instruction, no register and
 // no vector instruction spent), three stages deep.
-template <int BM, int BN>
+template <int BM, int BN, int NPL = 3>
 struct PlaneStage {
     static constexpr int KS = 16;
-    static constexpr int STAGES = 3;
+    static constexpr int STAGES = NPL == 2 ? 4 : 3;             // the two-plane stages are smaller: one more fits
     static constexpr int ROWB = 2 * KS;                         // bytes per row per plane
     static constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
-    static constexpr int STAGE_BYTES = 3 * (PLANE_A + PLANE_B);
+    static constexpr int STAGE_BYTES = NPL * (PLANE_A + PLANE_B);
     static constexpr int PIECES = STAGE_BYTES / 1024;           // wave instructions per stage
 };
 
@@ -489,12 +492,13 @@ constexpr int gemm_smem_floats()
 {
     constexpr int GT = 64 * WAVES_M * WAVES_N;
     constexpr int KS = (PREC == 3) ? 16 : BK;
-    constexpr int TPL = (PREC == 0 || PREC == 4) ? 1 : PREC;
+    constexpr int TPL = (PREC == 0 || PREC == 4 || PREC == 5) ? 1 : PREC;
     using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, TPL, KS>>::type;
     using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, TPL, KS>>::type;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
-    constexpr int MAIN = (PREC == 4) ? PlaneStage<BM, BN>::STAGES * PlaneStage<BM, BN>::STAGE_BYTES / 4
-                                     : KG * 2 * (TA::SIZE + TB::SIZE),
+    constexpr int MAIN = (PREC == 4)   ? PlaneStage<BM, BN, 3>::STAGES * PlaneStage<BM, BN, 3>::STAGE_BYTES / 4
+                         : (PREC == 5) ? PlaneStage<BM, BN, 2>::STAGES * PlaneStage<BM, BN, 2>::STAGE_BYTES / 4
+                                       : KG * 2 * (TA::SIZE + TB::SIZE),
                   EPI = KG * WAVES_M * WAVES_N * WTM * (WTN + 4);
     // + 4: the tail split's "last arriver" word lives behind the buffers, in the same array (a second __shared__
     // object beside an array that LDS-DMA fills makes the compiler drain all loads before every LDS read).  The
@@ -511,8 +515,8 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
     constexpr int GT = 64 * WAVES_M * WAVES_N;  // threads of one wave group
     constexpr int GW = WAVES_M * WAVES_N;
     // k extent of one pipeline step: the three-plane tiles take 16 so that two blocks still fit a CU's LDS
-    constexpr int KS = (PREC == 3 || PREC == 4) ? 16 : BK;
-    constexpr int TPL = (PREC == 0 || PREC == 4) ? 1 : PREC;  // planes of the register-staged bf16 tiles
+    constexpr int KS = (PREC == 3 || PREC == 4 || PREC == 5) ? 16 : BK;
+    constexpr int TPL = (PREC == 0 || PREC == 4 || PREC == 5) ? 1 : PREC;  // planes of the register-staged bf16 tiles
     using TA = typename std::conditional<PREC == 0, Tile<BM, AKC, GT>, TileB<BM, AKC, GT, TPL, KS>>::type;
     using TB = typename std::conditional<PREC == 0, Tile<BN, BKC, GT>, TileB<BN, BKC, GT, TPL, KS>>::type;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -652,13 +656,15 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         f16x2_scale(mb, sc_b, inv_b);
     }
 
-    if constexpr (PREC == 4) {
+    if constexpr (PREC == 4 || PREC == 5) {
         static_assert(KG == 1 && WAVES_M * WAVES_N == 4, "the plane pipeline is written for four waves");
-        using PS = PlaneStage<BM, BN>;
+        constexpr int NPL = PREC == 4 ? 3 : 2;  // three bf16 planes, or two fp16 ones
+        using PS = PlaneStage<BM, BN, NPL>;
         constexpr int PPW = PS::PIECES / 4;  // pieces (1 KB wave instructions) per wave and stage
         static_assert(PPW * 4 == PS::PIECES, "a stage must split evenly over the four waves");
+        static_assert(PS::STAGES == 3 || PS::STAGES == 4, "the waits below are written out for rings of three and four");
         char* const lds = reinterpret_cast<char*>(smem);
-        // this wave's pieces: piece q < 3 BM/32 is plane q / (BM/32), row block q % (BM/32) of A; the rest B alike.
+        // this wave's pieces: piece q < NPL BM/32 is plane q / (BM/32), row block q % (BM/32) of A; the rest B alike.
         // Lane l fetches 16 bytes: row (l >> 1) of the block, k half (l & 1).  Rows past the operand's last one are
         // clamped (their products land in rows / columns the epilogue never stores).
         const __bf16* src[PPW];
@@ -666,8 +672,8 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
 #pragma unroll
         for (int t = 0; t < PPW; ++t) {
             const int q = wave * PPW + t;
-            const bool isA = q < 3 * (BM / 32);
-            const int qq = isA ? q : q - 3 * (BM / 32);
+            const bool isA = q < NPL * (BM / 32);
+            const int qq = isA ? q : q - NPL * (BM / 32);
             const int rblocks = isA ? BM / 32 : BN / 32;
             const int pl = qq / rblocks, rb = qq % rblocks;
             const int row = rb * 32 + (lane >> 1);
@@ -680,7 +686,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
                 const int gc = min(n0 + row, a.N - 1);
                 src[t] = reinterpret_cast<const __bf16*>(B) + pl * a.planeB +
                          ((long long)(k_begin / KS) * a.ldb + gc) * KS + (lane & 1) * 8;
-                dst[t] = 3 * PS::PLANE_A + pl * PS::PLANE_B + rb * 1024;
+                dst[t] = NPL * PS::PLANE_A + pl * PS::PLANE_B + rb * 1024;
             }
         }
         const long long stepA = (long long)a.lda * KS, stepB = (long long)a.ldb * KS;  // elements per k step
@@ -688,28 +694,33 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
             char* stage = lds + (kt % PS::STAGES) * PS::STAGE_BYTES;
 #pragma unroll
             for (int t = 0; t < PPW; ++t) {
-                const bool isA = wave * PPW + t < 3 * (BM / 32);
+                const bool isA = wave * PPW + t < NPL * (BM / 32);
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(src[t] + kt * (isA ? stepA : stepB)),
                     (__attribute__((address_space(3))) void*)(stage + dst[t]), 16, 0, 0);
             }
         };
-        if (nk > 0) issue(0);
-        if (nk > 1) issue(1);
+#pragma unroll
+        for (int t = 0; t < PS::STAGES - 1; ++t)
+            if (nk > t) issue(t);
         for (int kt = 0; kt < nk; ++kt) {
-            // stage kt was issued two iterations ago; the only younger loads are stage kt + 1's
-            if (kt + 1 < nk)
+            // stage kt was issued STAGES - 1 iterations ago; the only younger loads are those of the up to
+            // STAGES - 2 stages after it
+            const int younger = min(PS::STAGES - 2, nk - 1 - kt);
+            if (younger >= 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (younger == 1)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // every wave's share of stage kt has landed, and every wave has finished reading stage kt - 1, whose
-            // buffer stage kt + 2 now overwrites
+            // buffer stage kt + STAGES - 1 now overwrites
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk) issue(kt + 2);
+            if (kt + PS::STAGES - 1 < nk) issue(kt + PS::STAGES - 1);
             const char* stage = lds + (kt % PS::STAGES) * PS::STAGE_BYTES;
-            bf16x8 fa[TM][3], fb[TN][3];
+            bf16x8 fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     fa[i][pl] = __builtin_bit_cast(
@@ -717,19 +728,19 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     fb[j][pl] = __builtin_bit_cast(
-                        bf16x8, *reinterpret_cast<const u32x4*>(stage + 3 * PS::PLANE_A + pl * PS::PLANE_B +
+                        bf16x8, *reinterpret_cast<const u32x4*>(stage + NPL * PS::PLANE_A + pl * PS::PLANE_B +
                                                                 (wn + 32 * j + r) * PS::ROWB + h * 16));
             }
-            // products of plane pairs (pa, pb) with pa + pb <= 2, the small ones first
+            // products of plane pairs (pa, pb) with pa + pb < NPL, the small ones first
 #pragma unroll
-            for (int sum = 2; sum >= 0; --sum)
+            for (int sum = NPL - 1; sum >= 0; --sum)
 #pragma unroll
                 for (int pa = 0; pa <= sum; ++pa)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma_16bit<NPL == 2>(fa[i][pa], fb[j][sum - pa], acc[i][j]);
         }
         __syncthreads();  // the epilogue reuses the stages
     } else if constexpr (PREC == 0 && KG > 1) {
@@ -1171,6 +1182,12 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
             xv[it] = t;
         }
     }
+    f32x4 ib = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (PREC == 5) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (gcol + q < a.N) ib[q] = a.inv_b_rows[gcol + q];
+    }
     f32x4 colacc = {0.f, 0.f, 0.f, 0.f};  // this lane's share of the column sums of the stored values
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1180,6 +1197,12 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
 #pragma unroll
         for (int g = 1; g < KG; ++g) v += *reinterpret_cast<const f32x4*>(&sC[g * GW * WTM * LDC + lrow * LDC + c4 * 4]);
         if (grow >= Mr || gcol >= a.N) continue;
+        if constexpr (PREC == 5) {
+            // undo the operands' row scales (powers of two: exact)
+            const float ia = a.inv_a_rows[grow];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (v[q] * ia) * ib[q];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float y = v[q] + bv[q];
@@ -1392,7 +1415,10 @@ int launch_cfg(const KArgs& k, bool akc, bool bkc, int grid, hipStream_t s)
 // C = A B^T with both operands given as three bf16 planes (GemmDesc::planes).
 int launch_planes(const KArgs& k, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 1, true, true, 4>), dim3(grid), dim3(256), 0, s, k);
+    if (k.inv_a_rows != nullptr)
+        hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 1, true, true, 5>), dim3(grid), dim3(256), 0, s, k);
+    else
+        hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 1, true, true, 4>), dim3(grid), dim3(256), 0, s, k);
     return check_launch("gemm_kernel(planes)");
 }
 
@@ -1513,12 +1539,16 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
             (reinterpret_cast<uintptr_t>(d.A) & 15) != 0 || (reinterpret_cast<uintptr_t>(d.B) & 15) != 0)
             return set_error(GTG_ERR_INVALID, "gemm: plane operands need batch 1, no split-K, K a multiple of 16 and "
                                               "16-byte aligned rows and planes");
+        if ((d.planes_inv_a == nullptr) != (d.planes_inv_b == nullptr))
+            return set_error(GTG_ERR_INVALID, "gemm: fp16 plane operands need the inverse scales of both");
     }
 
     KArgs& k = p.k;
     k.planeA = d.planeA;
     k.planeB = d.planeB;
     k.absmax = d.absmax_ws;
+    k.inv_a_rows = d.planes ? d.planes_inv_a : nullptr;
+    k.inv_b_rows = d.planes ? d.planes_inv_b : nullptr;
     k.A = d.A;
     k.B = d.B;
     k.C = d.C;
@@ -1630,7 +1660,7 @@ int gemm(const GemmDesc& d, hipStream_t s)
         // for them, and the batched forms, get the three-plane bf16 split (the same accuracy class)
         if (d.absmax_ws == nullptr || d.batch != 1 || d.batch_dim != nullptr || d.batch_off != nullptr) {
             prec = GTG_MATRIX_BF16X3;
-        } else {
+        } else if (!d.absmax_ready) {
             AbsmaxJob ja, jb;
             ja.p = d.A;
             ja.ld = d.lda;

@@ -631,16 +631,47 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4_t& p0, u32x4_t
     }
 }
 
+// x[0..7] * scale -> the eight fp16 of the value rounded to nearest and of what is left, rounded to nearest
+__device__ __forceinline__ void split8h(const float (&x)[8], float scale, u32x4_t& p0, u32x4_t& p1)
+{
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a0 = x[2 * q] * scale, b0 = x[2 * q + 1] * scale;
+        const f16x2_t hi = {(_Float16)a0, (_Float16)b0};
+        a0 -= (float)hi[0];
+        b0 -= (float)hi[1];
+        const f16x2_t lo = {(_Float16)a0, (_Float16)b0};
+        p0[q] = __builtin_bit_cast(unsigned, hi);
+        p1[q] = __builtin_bit_cast(unsigned, lo);
+    }
+}
+
+// maximum of a non-negative value over the block's 256 threads (sm: four floats of LDS; ends with a barrier)
+__device__ __forceinline__ float block_max256(float v, float* sm)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();  // an earlier use of sm has been read
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
 constexpr int GP_MAX_D = 1024;
 // blocks [0, pg_blocks): stage 1 of the prototype rows' gradient; block pg_blocks + b: graph b's rows
 // dT2c[off_b + j, c] = adj[b, am, j] * dpool[b, c], j < n_b.  A thread takes (row j, eight columns): 16-byte
 // stores, consecutive threads on consecutive rows of one k block (contiguous in the k-blocked layout).
+// F16: two fp16 planes instead, every row of the graph times one power of two (from the largest pooled gradient
+// times the largest adjacency entry of the graph, a bound on the rows' entries); inv_rows[row] = its inverse.
+template <bool F16>
 __global__ __launch_bounds__(256) void pool_bwd_gather_planes_kernel(
     const float* __restrict__ adj, const float* __restrict__ dpool, const int32_t* __restrict__ argmax,
     const int32_t* __restrict__ meta, int B, int n, int d, long long rows_alloc, unsigned short* __restrict__ planes,
-    int32_t* __restrict__ zero, int zero_count, float* __restrict__ pg_partial, int pg_blocks)
+    int32_t* __restrict__ zero, int zero_count, float* __restrict__ pg_partial, int pg_blocks, float* __restrict__ inv_rows)
 {
     __shared__ float sadj[64 * 65];
+    __shared__ float smax[4];
     __shared__ float gS[GP_MAX_D];
     __shared__ int amS[GP_MAX_D];
     if ((int)blockIdx.x < pg_blocks) {
@@ -660,6 +691,17 @@ __global__ __launch_bounds__(256) void pool_bwd_gather_planes_kernel(
         amS[c] = real ? am : 0;
     }
     __syncthreads();
+    float scale = 1.f;
+    if constexpr (F16) {
+        float mg = 0.f, ma = 0.f;
+        for (int c = tid; c < d; c += 256) mg = fmaxf(mg, fabsf(gS[c]));
+        for (int idx = tid; idx < nb * n; idx += 256) ma = fmaxf(ma, fabsf(sadj[(idx / n) * 65 + (idx % n)]));
+        mg = block_max256(mg, smax);
+        ma = block_max256(ma, smax);
+        float inverse;
+        f16x2_scale(mg * ma, scale, inverse);
+        for (int j = tid; j < nb; j += 256) inv_rows[off + j] = inverse;
+    }
     const int kblocks = d / 16;
     const long long plane = (long long)kblocks * rows_alloc * 16;
     const int items = kblocks * nb * 2;
@@ -669,12 +711,19 @@ __global__ __launch_bounds__(256) void pool_bwd_gather_planes_kernel(
         float x[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) x[u] = sadj[amS[c0 + u] * 65 + j] * gS[c0 + u];
-        u32x4_t p0, p1, p2;
-        split8(x, p0, p1, p2);
         unsigned short* dst = planes + ((long long)kb * rows_alloc + off + j) * 16 + half * 8;
-        *reinterpret_cast<u32x4_t*>(dst) = p0;
-        *reinterpret_cast<u32x4_t*>(dst + plane) = p1;
-        *reinterpret_cast<u32x4_t*>(dst + 2 * plane) = p2;
+        if constexpr (F16) {
+            u32x4_t p0, p1;
+            split8h(x, scale, p0, p1);
+            *reinterpret_cast<u32x4_t*>(dst) = p0;
+            *reinterpret_cast<u32x4_t*>(dst + plane) = p1;
+        } else {
+            u32x4_t p0, p1, p2;
+            split8(x, p0, p1, p2);
+            *reinterpret_cast<u32x4_t*>(dst) = p0;
+            *reinterpret_cast<u32x4_t*>(dst + plane) = p1;
+            *reinterpret_cast<u32x4_t*>(dst + 2 * plane) = p2;
+        }
     }
 }
 
@@ -733,6 +782,77 @@ __global__ __launch_bounds__(256) void proto_grad_stage2_planes(const float* __r
     *reinterpret_cast<u32x4_t*>(dst) = p0;
     *reinterpret_cast<u32x4_t*>(dst + plane) = p1;
     *reinterpret_cast<u32x4_t*>(dst + 2 * plane) = p2;
+}
+
+// The fp16 form of the kernel above.  Block i < n: prototype row i -- the ordered sum of its segments (kept as fp32
+// in proto_rows), its largest magnitude, and the row times the matching power of two as two fp16 planes at row
+// R + i; inv_rows[R + i] = the inverse.  Blocks from n on take 16 rows each of the weight operand (operand row r =
+// column r of w, depth = w_rows): the row's largest magnitude (first pass), then its planes (second pass over the
+// same cache-resident values); inv_w[r] = the row's inverse scale.
+__global__ __launch_bounds__(256) void proto_grad_stage2_planes_f16(const float* __restrict__ partial,
+                                                                    const int32_t* __restrict__ row_base, int n, int d,
+                                                                    long long rows_alloc, float* __restrict__ proto_rows,
+                                                                    unsigned short* __restrict__ planes,
+                                                                    float* __restrict__ inv_rows, const float* __restrict__ w,
+                                                                    int w_rows, int w_cols, int w_ld,
+                                                                    unsigned short* __restrict__ w_planes,
+                                                                    float* __restrict__ inv_w)
+{
+    __shared__ float sm[GP_MAX_D];
+    __shared__ float smax[4];
+    __shared__ unsigned rowmax[16];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= n) {
+        const int r = tid & 15, kq = tid >> 4, row = ((int)blockIdx.x - n) * 16 + r;
+        if (tid < 16) rowmax[tid] = 0u;
+        __syncthreads();
+        float m = 0.f;
+        if (row < w_cols)
+            for (int k = kq; k < w_rows; k += 16) m = fmaxf(m, fabsf(w[(long long)k * w_ld + row]));
+        atomicMax(&rowmax[r], __float_as_uint(m));  // non-negative floats order as their bit patterns
+        __syncthreads();
+        if (row >= w_cols) return;
+        float scale, inverse;
+        f16x2_scale(__uint_as_float(rowmax[r]), scale, inverse);
+        if (kq == 0) inv_w[row] = inverse;
+        const long long total = (long long)w_rows * w_cols;
+        for (int k = kq; k < w_rows; k += 16) {
+            const float t = w[(long long)k * w_ld + row] * scale;
+            const _Float16 hi = (_Float16)t, lo = (_Float16)(t - (float)hi);
+            const long long i = ((long long)(k >> 4) * w_cols + row) * 16 + (k & 15);
+            w_planes[i] = __builtin_bit_cast(unsigned short, hi);
+            w_planes[total + i] = __builtin_bit_cast(unsigned short, lo);
+        }
+        return;
+    }
+    const int i = blockIdx.x, total = n * d;
+    float m = 0.f;
+    for (int e = tid; e < d; e += 256) {
+        float v[PG_SEG];
+#pragma unroll
+        for (int k = 0; k < PG_SEG; ++k) v[k] = partial[(int64_t)k * total + i * d + e];
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < PG_SEG; ++k) acc += v[k];
+        proto_rows[i * d + e] = acc;
+        sm[e] = acc;
+        m = fmaxf(m, fabsf(acc));
+    }
+    m = block_max256(m, smax);
+    float scale, inverse;
+    f16x2_scale(m, scale, inverse);
+    if (tid == 0) inv_rows[row_base[0] + i] = inverse;
+    const long long plane = (long long)(d / 16) * rows_alloc * 16;
+    for (int c0 = tid * 8; c0 < d; c0 += 256 * 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = sm[c0 + u];
+        u32x4_t p0, p1;
+        split8h(x, scale, p0, p1);
+        unsigned short* dst = planes + ((long long)(c0 / 16) * rows_alloc + row_base[0] + i) * 16 + (c0 & 8);
+        *reinterpret_cast<u32x4_t*>(dst) = p0;
+        *reinterpret_cast<u32x4_t*>(dst + plane) = p1;
+    }
 }
 
 __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ out,
@@ -1111,17 +1231,30 @@ bool pool_bwd_gather_planes_applies(int n, int d) { return n >= 1 && n <= 64 && 
 // prototype rows also as fp32 (proto_rows, (n, d)).  d a multiple of 16, at most 1024.  The second launch also
 // splits the weight w ((w_rows, w_cols), leading dimension w_ld; w_rows a multiple of 16) into w_planes, laid out
 // as the GEMM's B operand for a product with w: (3, w_rows / 16, w_cols, 16).
+// With inv_rows / inv_w (both or neither): two fp16 planes per operand instead, each row scaled by a power of two,
+// inv_rows[row] (rows_alloc floats) and inv_w[w_cols] receiving the inverse scales.
 int pool_bwd_gather_planes(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta, int64_t B,
                            int n, int d, long long rows_alloc, void* planes, float* proto_rows, float* pg_partial,
                            int32_t* zero, int zero_count, const float* w, int w_rows, int w_cols, int w_ld,
-                           void* w_planes, hipStream_t s)
+                           void* w_planes, float* inv_rows, float* inv_w, hipStream_t s)
 {
-    if (!pool_bwd_gather_planes_applies(n, d) || B < 1 || w_rows % 16 != 0 || w_rows < 16 || w_cols < 1 || w_ld < w_cols)
+    if (!pool_bwd_gather_planes_applies(n, d) || B < 1 || w_rows % 16 != 0 || w_rows < 16 || w_cols < 1 || w_ld < w_cols ||
+        (inv_rows == nullptr) != (inv_w == nullptr))
         return set_error(GTG_ERR_INVALID, "pool_bwd_gather_planes: shape");
     const int pg_blocks = ((d + 63) / 64) * PG_SEG;
-    hipLaunchKernelGGL(pool_bwd_gather_planes_kernel, dim3((unsigned)(B + pg_blocks)), dim3(256), 0, s, adj, dpool, argmax,
-                       meta, (int)B, n, d, rows_alloc, reinterpret_cast<unsigned short*>(planes), zero, zero_count,
-                       pg_partial, pg_blocks);
+    if (inv_rows != nullptr) {
+        hipLaunchKernelGGL(pool_bwd_gather_planes_kernel<true>, dim3((unsigned)(B + pg_blocks)), dim3(256), 0, s, adj, dpool,
+                           argmax, meta, (int)B, n, d, rows_alloc, reinterpret_cast<unsigned short*>(planes), zero,
+                           zero_count, pg_partial, pg_blocks, inv_rows);
+        if (int rc = check_launch("pool_bwd_gather_planes_kernel")) return rc;
+        hipLaunchKernelGGL(proto_grad_stage2_planes_f16, dim3((unsigned)(n + (w_cols + 15) / 16)), dim3(256), 0, s, pg_partial,
+                           meta + 2 * B, n, d, rows_alloc, proto_rows, reinterpret_cast<unsigned short*>(planes), inv_rows, w,
+                           w_rows, w_cols, w_ld, reinterpret_cast<unsigned short*>(w_planes), inv_w);
+        return check_launch("proto_grad_stage2_planes_f16");
+    }
+    hipLaunchKernelGGL(pool_bwd_gather_planes_kernel<false>, dim3((unsigned)(B + pg_blocks)), dim3(256), 0, s, adj, dpool,
+                       argmax, meta, (int)B, n, d, rows_alloc, reinterpret_cast<unsigned short*>(planes), zero, zero_count,
+                       pg_partial, pg_blocks, (float*)nullptr);
     if (int rc = check_launch("pool_bwd_gather_planes_kernel")) return rc;
     const int stage2_blocks = (n * d + 255) / 256;
     const long long w_blocks = ((long long)w_rows * w_cols + 255) / 256;

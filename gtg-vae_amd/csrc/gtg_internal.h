@@ -84,12 +84,18 @@ struct GemmDesc {
     // K a multiple of 16, no split-K; m_dev, the tail split, every store epilogue and colsum_part apply.
     bool planes = false;
     long long planeA = 0, planeB = 0;
+    // The same with two fp16 planes per operand (images [2][K/16][rows][16]), every operand row scaled by a power of
+    // two: planes_inv_a[M] / planes_inv_b[N] hold the inverse scales, which the epilogue multiplies back in.
+    const float* planes_inv_a = nullptr;
+    const float* planes_inv_b = nullptr;
     // GTG_MATRIX_F16X2 on the 128x128 / 256x128 configurations: GEMM_ABSMAX_BYTES of device scratch for the
     // operands' partial maxima (written by a launch of its own right before the GEMM's; calls on one stream may
     // share it).  Without it such a product runs the three-plane bf16 split instead.
     float* absmax_ws = nullptr;
     // optional: a bound the caller knows on the magnitudes of A / B (> 0), which saves that operand's pass
     float a_bound = 0.f, b_bound = 0.f;
+    // absmax_ws already holds both operands' partial maxima (the producer of A left them): no pass at all
+    bool absmax_ready = false;
 };
 constexpr int GEMM_ABSMAX_PARTS = 1024;
 constexpr size_t GEMM_ABSMAX_BYTES = 2 * GEMM_ABSMAX_PARTS * sizeof(float);
@@ -187,7 +193,7 @@ bool pool_bwd_gather_planes_applies(int n, int d);
 int pool_bwd_gather_planes(const float* adj, const float* dpool, const int32_t* argmax, const int32_t* meta, int64_t B,
                            int n, int d, long long rows_alloc, void* planes, float* proto_rows, float* pg_partial,
                            int32_t* zero, int zero_count, const float* w, int w_rows, int w_cols, int w_ld, void* w_planes,
-                           hipStream_t s);
+                           float* inv_rows, float* inv_w, hipStream_t s);
 int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z,
                float* kl_partial, float* kl_out, hipStream_t s);
 // dmu / dlogvar rows have stride ld_out (d, or 2d when they are the two halves of one (B, 2d) matrix)
@@ -217,7 +223,7 @@ int edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gold_bi
 // ---- first GCN layer on identity features as sparse row products (gcn_sparse.hip) ----
 // h1c[r] = relu(b1 + sum_k adjc[r,k] W1[:,k]) for r < min(rows_max, *rows_dev); H a multiple of 4
 int conv1_sparse(const float* adjc, int n, const float* W1, const float* b1, int H, const int* rows_dev, int rows_max,
-                 float* h1c, hipStream_t s);
+                 float* h1c, float* absmax, const float* w_next, long long w_next_count, hipStream_t s);
 
 // pooled (B, d) / argmax = max over the rows r < n_b of A_b T2c_b + b2, merged with the prototype rows' maximum;
 // meta as written by graph_meta; d a multiple of 4
