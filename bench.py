@@ -227,9 +227,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mst", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sub-records of configurations A, B and the joint step")
-    ap.add_argument("--matrix", choices=["f32", "bf16x3", "f16x2", "bf16"], default="bf16x3",
+    ap.add_argument("--matrix", choices=["f32", "bf16x3", "f16x2", "bf16"], default="f16x2",
                     help="matrix pipe of the large encoder GEMMs: fp32 MFMA; the exact three-way bf16 split on the bf16 "
-                         "MFMA (fp32-level error, default); plain bf16 operands (loss tolerance 1e-3)")
+                         "MFMA; the scaled two-way fp16 split on the fp16 MFMA (both fp32-level error; f16x2 is the "
+                         "default); plain bf16 operands (loss tolerance 1e-3)")
     ap.add_argument("--no-alt", action="store_true", help="skip the short extra runs in the other matrix modes")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying HIP graphs")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager steps after the timed region, for per-kernel HIP-event times")
@@ -360,8 +361,7 @@ def main():
             # MFMA products actually issued (six per multiply-add for the three-way split)
             on_bf16 = args.matrix != "f32" and name.startswith("gemm128")
             peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_F32_MFMA_TFLOPS
-            # (operands that arrive as pre-split bf16 planes run the six products of the three-way split in f16x2 too)
-            products = 6 if (args.matrix == "f16x2" and "_planes" in name) else MODE_PRODUCTS[args.matrix]
+            products = MODE_PRODUCTS[args.matrix]
             issued = ach * (products if on_bf16 else 1)
             roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s",
                     "frac": issued / peak, "traffic": traffic, "traffic_source": PMC_SOURCE_NOTE, "kernel": name,
@@ -396,10 +396,11 @@ def main():
                                                  "exactly into three bf16 pieces and sum six piece products on the bf16 MFMA "
                                                  "with fp32 accumulation (error vs float64 equal to the fp32 MFMA's; the "
                                                  "parity tests run at the fp32 tolerances in this mode)",
-                                       "f16x2": "fp32 operands and results; the encoder's forward product scales every "
-                                                "operand by a power of two, splits it into two fp16 pieces and sums three "
-                                                "piece products on the fp16 MFMA; its backward product runs on pre-split "
-                                                "bf16 planes as in bf16x3 (error vs float64 equal to the fp32 MFMA's)",
+                                       "f16x2": "fp32 operands and results; the large encoder GEMMs scale every operand (row) "
+                                                "by a power of two, split it into two fp16 pieces (round to nearest twice) "
+                                                "and sum three piece products on the fp16 MFMA with fp32 accumulation, the "
+                                                "result scaled back exactly (error vs float64 equal to the fp32 MFMA's; the "
+                                                "parity tests run at the fp32 tolerances in this mode)",
                                        "bf16": "large encoder GEMMs on bf16-rounded operands, fp32 accumulation "
                                                "(loss tolerance 1e-3)"}[args.matrix]},
             "step_executed": {"gemm_gflop_per_step": gemm_flops / 1e9,
@@ -417,7 +418,7 @@ def main():
         if world == 1 and not args.no_alt:
             # the same loop in the other matrix modes (short, after the headline measurement)
             alt = {}
-            for mode in ("f32", "bf16x3", "bf16"):
+            for mode in ("f32", "bf16x3", "f16x2", "bf16"):
                 if mode == args.matrix:
                     continue
                 tr.matrix_mode = _lib.matrix_mode(mode)

@@ -75,9 +75,7 @@ EXPORTS = tuple(_SIGS)
 # Matrix pipe of the large GEMMs (include/gtgvae.h, GTG_MATRIX_*).  "bf16x3" splits every fp32 operand exactly
 # into three bf16 pieces and runs six products on the bf16 matrix cores with fp32 accumulation: the same error as
 # the fp32 pipe at 1.5x its speed.  "f16x2" (the default) scales every operand by a power of two and splits it
-# into two fp16 pieces, three products: the same error again with half the matrix instructions; products the
-# library runs on pre-split bf16 planes (the graph encoder's, the LSTM recurrence) are the "bf16x3" ones in
-# either mode.
+# into two fp16 pieces, three products: the same error again with half the matrix instructions.
 MATRIX_MODES = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3}
 _default_matrix_mode = MATRIX_MODES["f16x2"]   # changed only through set_default_matrix_mode()
 

@@ -55,9 +55,11 @@ extern "C" {
  *                      fp32 accumulation and the result is scaled back: the same error
  *                      against float64 as GTG_MATRIX_BF16X3 with half its matrix
  *                      instructions.  Values below 2^-28 of an operand's largest lose relative
- *                      precision (not absolute); Inf operands give NaN.  Products whose
- *                      operands arrive pre-split as bf16 planes, the batched forms and the LSTM
- *                      recurrence run the GTG_MATRIX_BF16X3 arithmetic in this mode.
+ *                      precision (not absolute); Inf operands give NaN.  Where a producer
+ *                      kernel hands the product its operands already split (the graph encoder's
+ *                      backward, the LSTM recurrence) the scale is per operand row and comes
+ *                      from that kernel.  The batched forms, and a GEMM call without the scratch
+ *                      for the maxima, run the GTG_MATRIX_BF16X3 arithmetic in this mode.
  *   GTG_MATRIX_BF16    operands rounded to bf16 (round to nearest even), one product:
  *                      about 3e-3 of max|C|; for loss tolerances of 1e-3. */
 /* The encoder entry points launch one grid row per graph: at most this many graphs per call. */

@@ -9,7 +9,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"]
         if flt and flt not in k:
             continue
-        acc[k[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[k[:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k)
     for c, v in sorted(cs.items()):

@@ -19,6 +19,12 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_
   python3 $repo/tools/pmc_summary.py $out/pmc_gemm_$n gemm_kernel > $out/${tag}_pmc_${n}_gemm128_planes.txt
   cp $out/pmc_gemm_$n/*/*counter_collection.csv $out/${tag}_pmc_${n}_gemm128_planes.csv
 done
+# the default (f16x2) step's two large GEMMs, from eager steps of the bench itself
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | cut -d" " -f1)
+  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_step_$n -- python3 $repo/bench.py --eager --steps 3 --warmup 1 --profile-steps 0 --no-extra --no-cpu-baseline --no-mst --no-alt > $out/pmc_step_$n.log 2>&1
+  python3 $repo/tools/pmc_summary.py $out/pmc_step_$n "gemm_kernel<128, 128, 2, 2, 1, true, true, " > $out/${tag}_pmc_${n}_step_gemm128.txt
+done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_mst_$c -- python3 $repo/tools/mst_bench.py 3 > $out/pmc_mst_$c.log 2>&1
   python3 $repo/tools/pmc_summary.py $out/pmc_mst_$c mst_kernel > $out/${tag}_pmc_${c}_mst_triu.txt
