@@ -1321,7 +1321,8 @@ struct AbsmaxJob {
     int rows, cols;
     const int* rows_dev;
     const int* cols_dev;
-    float bound;  // > 0: the caller's bound on the operand's magnitudes is taken instead of a pass over it
+    float bound;  // > 0: the caller's bound on the operand's magnitudes is taken instead of a pass over it;
+                  // < 0: the operand's slots already hold valid maxima and are left alone
 };
 
 __global__ __launch_bounds__(256) void absmax_pair_kernel(const AbsmaxJob ja, const AbsmaxJob jb, float* __restrict__ out)
@@ -1330,8 +1331,8 @@ __global__ __launch_bounds__(256) void absmax_pair_kernel(const AbsmaxJob ja, co
     const bool second = (int)blockIdx.x >= ABSMAX_PARTS;
     const AbsmaxJob j = second ? jb : ja;
     const int part = (int)blockIdx.x - (second ? ABSMAX_PARTS : 0), tid = threadIdx.x;
-    if (j.bound > 0.f) {
-        if (tid == 0) out[blockIdx.x] = j.bound;
+    if (j.bound != 0.f) {
+        if (tid == 0 && j.bound > 0.f) out[blockIdx.x] = j.bound;
         return;
     }
     int rows = j.rows, cols = j.cols;
@@ -1668,7 +1669,7 @@ int gemm(const GemmDesc& d, hipStream_t s)
             ja.cols = d.a_kc ? d.K : d.M;
             ja.rows_dev = d.a_kc ? d.m_dev : d.k_dev;
             ja.cols_dev = d.a_kc ? d.k_dev : d.m_dev;
-            ja.bound = d.a_bound;
+            ja.bound = d.a_partials_ready ? -1.f : d.a_bound;
             jb.bound = d.b_bound;
             jb.p = d.B;
             jb.ld = d.ldb;

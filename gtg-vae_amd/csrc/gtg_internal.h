@@ -96,6 +96,9 @@ struct GemmDesc {
     float a_bound = 0.f, b_bound = 0.f;
     // absmax_ws already holds both operands' partial maxima (the producer of A left them): no pass at all
     bool absmax_ready = false;
+    // absmax_ws already holds partial maxima that bound A (left by an earlier product on the same or a larger
+    // array): only B is walked
+    bool a_partials_ready = false;
 };
 constexpr int GEMM_ABSMAX_PARTS = 1024;
 constexpr size_t GEMM_ABSMAX_BYTES = 2 * GEMM_ABSMAX_PARTS * sizeof(float);

@@ -738,6 +738,10 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
 
     const int TB = T * B;
     if (int rc = colsum(w.dG, TB, 4 * H, 4 * H, w.cs, db, s)) return rc;
+    // the gate gradients are the A operand of every product below: their maxima (two-plane fp16 mode) are taken once
+    const bool dg_maxima = g_matrix_mode == GTG_MATRIX_F16X2;
+    if (dg_maxima)
+        if (int rc = absmax_partials(w.dG, TB, 4ll * H, 4ll * H, w.absmax, s)) return rc;
     GemmDesc g;
     // dW_ih = dG^T X
     g.A = w.dG; g.lda = 4 * H; g.a_kc = false;
@@ -745,6 +749,7 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
     g.C = dw_ih; g.ldc = I; g.M = 4 * H; g.N = I; g.K = TB;
     g.splits = gemm_pick_splits(4 * H, I, TB, 1); g.slabs = w.gemm_slabs;
     g.absmax_ws = w.absmax;
+    g.a_partials_ready = dg_maxima;
     if (int rc = gemm(g, s)) return rc;
     // dW_hh = sum over steps of dG_t^T h_(previous step): a contiguous run of steps in both buffers, plus the
     // first step against h0
@@ -755,6 +760,7 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = (T - 1) * B;
         g.splits = gemm_pick_splits(4 * H, H, (T - 1) * B, 1); g.slabs = w.gemm_slabs;
         g.absmax_ws = w.absmax;
+        g.a_partials_ready = dg_maxima;  // (a bound for any run of its steps)
         g.b_bound = 1.f;  // hidden states
         if (int rc = gemm(g, s)) return rc;
     } else if (int rc = clear_i32(reinterpret_cast<int32_t*>(dw_hh), total, s)) {  // one step and no h0 term yet: zero
@@ -767,6 +773,7 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         g.C = dw_hh; g.ldc = H; g.M = 4 * H; g.N = H; g.K = B;
         g.epi = EPI_ACCUM;
         g.absmax_ws = w.absmax;
+        g.a_partials_ready = dg_maxima;
         if (int rc = gemm(g, s)) return rc;
     }
     if (dx) {
@@ -775,6 +782,7 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         g.B = w_ih; g.ldb = I; g.b_kc = false;
         g.C = dx; g.ldc = I; g.M = TB; g.N = I; g.K = 4 * H;
         g.absmax_ws = w.absmax;
+        g.a_partials_ready = dg_maxima;
         if (int rc = gemm(g, s)) return rc;
     }
     return GTG_OK;
