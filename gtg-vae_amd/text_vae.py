@@ -48,6 +48,14 @@ class DAE(TextModel):
         self.E.flatten_parameters()
         self.G.flatten_parameters()
 
+    def _side_stream(self, device):
+        """A second stream on ``device`` (one per module and device), for work that runs beside the current stream."""
+        streams = self.__dict__.setdefault("_side_streams", {})
+        key = torch.device(device).index
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]
+
     def run_lstm(self, mod, emb, hidden=None, need_output=True):
         """``mod(emb, hidden)`` for a one-layer ``nn.LSTM``: through functional.lstm, one call per direction, when
         the input is fp32 on a GPU, the matrix mode is one of the bf16-pipe ones and the sizes fit; else the stock
@@ -58,16 +66,32 @@ class DAE(TextModel):
         if not (emb.is_cuda and emb.dtype == torch.float32 and mode != _lib.MATRIX_MODES["f32"] and
                 mod.num_layers == 1 and Fn.lstm_applies(T, B, I, H)):
             return mod(emb, hidden)
-        outs, hn, cn = [], [], []
-        for d in range(2 if mod.bidirectional else 1):
+        def one_direction(d):
             sfx = "_l0_reverse" if d else "_l0"
             h0 = hidden[0][d] if hidden is not None else None
             c0 = hidden[1][d] if hidden is not None else None
-            hs, hT, cT = Fn.lstm(emb, getattr(mod, "weight_ih" + sfx), getattr(mod, "weight_hh" + sfx),
-                                 getattr(mod, "bias_ih" + sfx), getattr(mod, "bias_hh" + sfx), h0, c0, bool(d), mode)
-            outs.append(hs)
-            hn.append(hT)
-            cn.append(cT)
+            return Fn.lstm(emb, getattr(mod, "weight_ih" + sfx), getattr(mod, "weight_hh" + sfx),
+                           getattr(mod, "bias_ih" + sfx), getattr(mod, "bias_hh" + sfx), h0, c0, bool(d), mode)
+
+        if mod.bidirectional:
+            # The two directions are independent and each step of a recurrence is one short launch with a block
+            # per CU, far from filling it: the reverse direction runs on a second stream beside the forward one
+            # (autograd runs each direction's backward on the stream of its forward, so the backward recurrences
+            # overlap the same way).
+            cur = torch.cuda.current_stream(emb.device)
+            side = self._side_stream(emb.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                emb.record_stream(side)
+                rev = one_direction(1)
+                for t in rev:
+                    t.record_stream(cur)
+            fwd = one_direction(0)
+            cur.wait_stream(side)
+            results = [fwd, rev]
+        else:
+            results = [one_direction(0)]
+        outs, hn, cn = [r[0] for r in results], [r[1] for r in results], [r[2] for r in results]
         output = None
         if need_output:
             output = outs[0] if len(outs) == 1 else torch.cat(outs, 2)
