@@ -222,6 +222,27 @@ def test_f16x2_pipe_rescales_tiny_and_huge_operands(sa, sb):
         assert ((got.double() - want).abs() / scale).max().item() < 2e-6
 
 
+def test_f16x2_pipe_ignores_what_lies_past_the_device_side_extent():
+    """Rows of A past the count in device memory may hold anything -- huge values, NaN: the pass that finds the
+    operands' largest magnitudes must not read them, or the scale would flush the live rows' values (or poison
+    them).  (The depth cap of the weight-gradient form is exercised by the projection tests, whose pad rows
+    leave stale rows behind the kept ones.)"""
+    from gtg_vae_amd import functional as Fn
+
+    torch.manual_seed(23)
+    M, N, K, rows = 4224, 640, 384, 4100
+    rd = torch.tensor([rows], dtype=torch.int32, device="cuda")
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda")
+    A[rows:] = float("nan")
+    A[rows:, ::2] = 3e37
+    got = Fn.gemm_rows(A, B, True, True, rows_dev=rd, matrix_mode="f16x2")
+    want = A[:rows].double() @ B.double().t()
+    scale = A[:rows].double().abs() @ B.double().abs().t()
+    assert ((got[:rows].double() - want).abs() / scale).max().item() < 2e-6
+    assert bool((got[rows:] == 0).all())
+
+
 def _unblock(p):
     """(3, K/16, R, 16) k-blocked planes -> (3, R, K)."""
     return p.permute(0, 2, 1, 3).reshape(3, p.shape[2], -1)

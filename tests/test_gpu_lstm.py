@@ -110,6 +110,31 @@ def test_lstm_random_shapes_match_oracle():
             assert _relerr(a.grad, b.grad) < 1e-4, (tag, _relerr(a.grad, b.grad))
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_lstm_initial_state_of_any_magnitude(mode):
+    """An initial hidden state is not bounded by 1 like the states the recurrence produces (the two-plane fp16
+    mode scales each of its rows by that row's largest magnitude): rows of very different size, one all zero."""
+    from gtg_vae_amd import functional as Fn
+    from oracle import textvae_oracle as TO
+
+    T, B, I, H = 4, 9, 16, 128
+    g = torch.Generator().manual_seed(17)
+    w_ih, w_hh, b_ih, b_hh = _params(I, H, 19, 1.0 / H ** 0.5)
+    x = torch.randn(T, B, I, generator=g)
+    h0 = torch.randn(B, H, generator=g) * torch.tensor([1e-6, 1e-3, 0.0, 1.0, 40.0, 3e3, 0.5, 1e-9, 7.0]).view(B, 1)
+    c0 = torch.randn(B, H, generator=g)
+    d_hs = torch.randn(T, B, H, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh, h0, c0)]
+    out, _, _ = TO.lstm(*leaves[:5], leaves[5], leaves[6], False)
+    (out * d_hs).sum().backward()
+    cu = [t.clone().cuda().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh, h0, c0)]
+    hs, _, _ = Fn.lstm(*cu[:5], cu[5], cu[6], False, mode)
+    (hs * d_hs.cuda()).sum().backward()
+    assert _relerr(hs, out) < 1e-5
+    for name, a, b in zip(("x", "w_ih", "w_hh", "b_ih", "b_hh", "h0", "c0"), cu, leaves):
+        assert _relerr(a.grad, b.grad) < 1e-4, (name, _relerr(a.grad, b.grad))
+
+
 def test_lstm_final_state_only_gradient():
     """The encoder's use (text_vae.py:57-58): only h_n feeds the loss, the output sequence gets no gradient."""
     from gtg_vae_amd import functional as Fn
