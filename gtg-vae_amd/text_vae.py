@@ -4,11 +4,12 @@ Mirrors /root/reference/src/text_vae.py:22-132 (``TextModel``, ``DAE``): same
 sub-module names and shapes, hence the same ``state_dict`` keys
 (``embed, proj, E, G, hgen, z2emb``).  Embeddings run on stock PyTorch-ROCm
 kernels.  The LSTMs keep their parameters in ``nn.LSTM`` modules (same
-``state_dict`` keys) but on a GPU, in the bf16-pipe matrix modes (the default
-three-plane one and plain bf16), their forward and backward run through the
-library's own recurrence (``functional.lstm``: one fused product + cell
-launch per time step); the fp32 matrix mode and sizes the recurrence does
-not take use the stock module.  The vocabulary projection with its cross-entropy and arg-max -- most
+``state_dict`` keys) but on a GPU, in the 16-bit-pipe matrix modes (the default
+scaled two-plane fp16 one, the three-plane bf16 one and plain bf16), their
+forward and backward run through the library's own recurrence
+(``functional.lstm``: one fused product + cell launch per time step, the two
+directions of the encoder on two streams); the fp32 matrix mode and sizes the
+recurrence does not take use the stock module.  The vocabulary projection with its cross-entropy and arg-max -- most
 of the branch's arithmetic, 2*1024*vocab per token -- has a HIP path of its
 own, ``decode_loss``: it skips the pad tokens' rows in all three GEMMs and
 never holds more than one copy of the logits.
@@ -20,6 +21,9 @@ import torch.nn.functional as F
 from . import _lib
 from . import functional as Fn
 from .noise import noisy
+
+
+_SIDE_STREAMS = {}   # device index -> torch.cuda.Stream (DAE._side_stream)
 
 
 class TextModel(nn.Module):
@@ -48,13 +52,14 @@ class DAE(TextModel):
         self.E.flatten_parameters()
         self.G.flatten_parameters()
 
-    def _side_stream(self, device):
-        """A second stream on ``device`` (one per module and device), for work that runs beside the current stream."""
-        streams = self.__dict__.setdefault("_side_streams", {})
+    @staticmethod
+    def _side_stream(device):
+        """A second stream on ``device`` (one per device, kept outside the module so that the module still copies
+        and pickles), for work that runs beside the current stream."""
         key = torch.device(device).index
-        if key not in streams:
-            streams[key] = torch.cuda.Stream(device=device)
-        return streams[key]
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        return _SIDE_STREAMS[key]
 
     def run_lstm(self, mod, emb, hidden=None, need_output=True):
         """``mod(emb, hidden)`` for a one-layer ``nn.LSTM``: through functional.lstm, one call per direction, when
