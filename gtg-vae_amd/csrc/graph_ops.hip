@@ -786,9 +786,9 @@ __global__ __launch_bounds__(256) void proto_grad_stage2_planes(const float* __r
 
 // The fp16 form of the kernel above.  Block i < n: prototype row i -- the ordered sum of its segments (kept as fp32
 // in proto_rows), its largest magnitude, and the row times the matching power of two as two fp16 planes at row
-// R + i; inv_rows[R + i] = the inverse.  Blocks from n on take 16 rows each of the weight operand (operand row r =
-// column r of w, depth = w_rows): the row's largest magnitude (first pass), then its planes (second pass over the
-// same cache-resident values); inv_w[r] = the row's inverse scale.
+// R + i; inv_rows[R + i] = the inverse.  Blocks from n on take four rows each of the weight operand (operand row r =
+// column r of w, depth = w_rows <= GP_MAX_D): the row's largest magnitude, then its planes; inv_w[r] = the row's
+// inverse scale.
 __global__ __launch_bounds__(256) void proto_grad_stage2_planes_f16(const float* __restrict__ partial,
                                                                     const int32_t* __restrict__ row_base, int n, int d,
                                                                     long long rows_alloc, float* __restrict__ proto_rows,
@@ -803,21 +803,33 @@ __global__ __launch_bounds__(256) void proto_grad_stage2_planes_f16(const float*
     __shared__ unsigned rowmax[16];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= n) {
-        const int r = tid & 15, kq = tid >> 4, row = ((int)blockIdx.x - n) * 16 + r;
-        if (tid < 16) rowmax[tid] = 0u;
+        // four operand rows per block, 64 threads per row, up to 16 depth values per thread held in registers
+        // (w_rows <= GP_MAX_D): every load is in flight before the first is used
+        const int r = tid & 3, kq = tid >> 2, row = ((int)blockIdx.x - n) * 4 + r;
+        if (tid < 4) rowmax[tid] = 0u;
         __syncthreads();
+        const bool row_ok = row < w_cols;
+        float v[GP_MAX_D / 64];
+#pragma unroll
+        for (int q = 0; q < GP_MAX_D / 64; ++q) {
+            const int k = kq + 64 * q;
+            v[q] = (row_ok && k < w_rows) ? w[(long long)k * w_ld + row] : 0.f;
+        }
         float m = 0.f;
-        if (row < w_cols)
-            for (int k = kq; k < w_rows; k += 16) m = fmaxf(m, fabsf(w[(long long)k * w_ld + row]));
+#pragma unroll
+        for (int q = 0; q < GP_MAX_D / 64; ++q) m = fmaxf(m, fabsf(v[q]));
         atomicMax(&rowmax[r], __float_as_uint(m));  // non-negative floats order as their bit patterns
         __syncthreads();
-        if (row >= w_cols) return;
+        if (!row_ok) return;
         float scale, inverse;
         f16x2_scale(__uint_as_float(rowmax[r]), scale, inverse);
         if (kq == 0) inv_w[row] = inverse;
         const long long total = (long long)w_rows * w_cols;
-        for (int k = kq; k < w_rows; k += 16) {
-            const float t = w[(long long)k * w_ld + row] * scale;
+#pragma unroll
+        for (int q = 0; q < GP_MAX_D / 64; ++q) {
+            const int k = kq + 64 * q;
+            if (k >= w_rows) break;
+            const float t = v[q] * scale;
             const _Float16 hi = (_Float16)t, lo = (_Float16)(t - (float)hi);
             const long long i = ((long long)(k >> 4) * w_cols + row) * 16 + (k & 15);
             w_planes[i] = __builtin_bit_cast(unsigned short, hi);
@@ -1247,7 +1259,8 @@ int pool_bwd_gather_planes(const float* adj, const float* dpool, const int32_t* 
                            argmax, meta, (int)B, n, d, rows_alloc, reinterpret_cast<unsigned short*>(planes), zero,
                            zero_count, pg_partial, pg_blocks, inv_rows);
         if (int rc = check_launch("pool_bwd_gather_planes_kernel")) return rc;
-        hipLaunchKernelGGL(proto_grad_stage2_planes_f16, dim3((unsigned)(n + (w_cols + 15) / 16)), dim3(256), 0, s, pg_partial,
+        if (w_rows > GP_MAX_D) return set_error(GTG_ERR_INVALID, "pool_bwd_gather_planes: weight depth above %d", GP_MAX_D);
+        hipLaunchKernelGGL(proto_grad_stage2_planes_f16, dim3((unsigned)(n + (w_cols + 3) / 4)), dim3(256), 0, s, pg_partial,
                            meta + 2 * B, n, d, rows_alloc, proto_rows, reinterpret_cast<unsigned short*>(planes), inv_rows, w,
                            w_rows, w_cols, w_ld, reinterpret_cast<unsigned short*>(w_planes), inv_w);
         return check_launch("proto_grad_stage2_planes_f16");
