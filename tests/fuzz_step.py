@@ -59,11 +59,13 @@ for c in range(cases):
         top2 = nodes.topk(min(2, N), dim=1).values
         flipped = (nodes.gather(1, won.view(B, 1, d)).squeeze(1) != top2[:, 0]).nonzero()
         if len(flipped):
-            leads = [(top2[b_, 0, c_] - nodes[b_, won[b_, c_], c_]).abs().item() / max(abs(top2[b_, 0, c_].item()), 1e-30)
+            # a lead is measured against the graph's largest node value: rounding acts on the products' size, and a
+            # maximum that happens to lie near zero would make a lead relative to itself meaningless
+            leads = [(top2[b_, 0, c_] - nodes[b_, won[b_, c_], c_]).abs().item() / max(nodes[b_].abs().max().item(), 1e-30)
                      for b_, c_ in flipped.tolist()]
             # (structurally equivalent nodes -- two leaves of one parent -- give exactly equal rows, which the
             # oracle's scatter sums may separate by an ulp: such twins account for most flips at small N)
-            assert max(leads) <= 3e-6 and len(flipped) <= 8 + B * d // 1000, (
+            assert max(leads) <= 1e-6 and len(flipped) <= 8 + B * d // 1000, (
                 "case %d B=%d N=%d d=%d hid=%d: %d flips, largest lead %.2e" % (c, B, N, d, hid, len(flipped), max(leads)))
             want = {k: v.clone().requires_grad_(True) for k, v in params.items()}
             O.graph_step_loss(want, None, batch.edge_index, batch.adj_padded, eps, kl_w, B, N, won)[0].backward()
