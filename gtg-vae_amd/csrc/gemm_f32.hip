@@ -1519,7 +1519,6 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
     if (d.epi == EPI_MASK && !d.aux) return set_error(GTG_ERR_INVALID, "gemm: mask epilogue without aux");
 
     TileCfg cfg = d.planes ? CFG_128 : pick_cfg(d.M, d.N, d.K, d.batch, d.epi);
-#ifndef GTG_NO_256X128
     // Large products on the bf16 pipes: a 256x128 tile shared by eight waves (one block per CU) moves a quarter
     // less operand data per multiply-add than the 128x128 tile, through global memory, the split arithmetic and
     // the LDS stores alike.  Taken when it still gives every CU at least two tiles; a caller that offers a tail
@@ -1531,7 +1530,6 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
         (g_matrix_mode == GTG_MATRIX_BF16X3 || g_matrix_mode == GTG_MATRIX_BF16 || g_matrix_mode == GTG_MATRIX_F16X2) && d.batch == 1 && d.splits <= 1 && d.colsum_part == nullptr && d.epi != EPI_POOL &&
         (long long)((d.M + 255) / 256) * ((d.N + 127) / 128) >= (d.tail_ws != nullptr ? 2048 : 512))
         cfg = CFG_256x128;
-#endif
     int bm, bn;
     cfg_dims(cfg, bm, bn);
     if (d.planes) {
