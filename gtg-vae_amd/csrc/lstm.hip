@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
                                                             int Z, const float* __restrict__ d_cT, int first,
                                                             float* __restrict__ dc_io, float* __restrict__ dG,
                                                             __bf16* __restrict__ dG_planes, long long plane, int M, int H,
-                                                            float* __restrict__ inv_rows)
+                                                            float* __restrict__ inv_rows, unsigned* __restrict__ dg_max)
 {
     __shared__ unsigned rowmax[16];
     const long long MH = (long long)M * H;
@@ -469,7 +469,12 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
         if (!active) return;
         float scale, inverse;
         f16x2_scale(__uint_as_float(rowmax[rl]), scale, inverse);
-        if (u0 == 0) inv_rows[row] = inverse;
+        if (u0 == 0) {
+            inv_rows[row] = inverse;
+            // the running maxima of all steps' gate gradients, for the large products that follow the recurrence
+            // (GEMM_ABSMAX_PARTS slots, cleared by the caller; non-negative floats order as their bit patterns)
+            if (dg_max != nullptr) atomicMax(&dg_max[row & (GEMM_ABSMAX_PARTS - 1)], rowmax[rl]);
+        }
         *reinterpret_cast<f32x4*>(dc_io + i) = dcp;
         float* drow = dG + (long long)row * 4 * H + u0;
         *reinterpret_cast<f32x4*>(drow) = di;
@@ -694,6 +699,9 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
                                (const float*)nullptr, (float*)nullptr);
         }
         if (int rc = check_launch("lstm_wsplit_kernel")) return rc;
+        // (W_hh's maxima have been consumed: the slots now collect the gate gradients' maxima step by step)
+        if (f16)
+            if (int rc = clear_i32(reinterpret_cast<int32_t*>(w.absmax), GEMM_ABSMAX_PARTS, s)) return rc;
     }
 
     const int Z = bwd_slabs(B, H);
@@ -716,13 +724,13 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
             hipLaunchKernelGGL(lstm_cell_bwd_kernel<true>, dim3(cell_blocks_f16), dim3(256), 0, s, gates + (long long)t * 4 * BH,
                                cs + t * BH, st == 0 ? c0 : cs + tp * BH, d_hs ? d_hs + t * BH : nullptr, first ? d_hT : nullptr,
                                w.slabs, first ? 0 : Z, d_cT, first ? 1 : 0, w.dc, w.dG + (long long)t * 4 * BH, w.dgp, 4ll * BH, B,
-                               H, w.a_inv);
+                               H, w.a_inv, reinterpret_cast<unsigned*>(w.absmax));
             if (st > 0 || dh0 != nullptr) hipLaunchKernelGGL((lstm_step_kernel<false, 2>), grid, dim3(256), 0, s, a);
         } else {
             hipLaunchKernelGGL(lstm_cell_bwd_kernel<false>, dim3(cell_blocks), dim3(256), 0, s, gates + (long long)t * 4 * BH,
                                cs + t * BH, st == 0 ? c0 : cs + tp * BH, d_hs ? d_hs + t * BH : nullptr, first ? d_hT : nullptr,
                                w.slabs, first ? 0 : Z, d_cT, first ? 1 : 0, w.dc, w.dG + (long long)t * 4 * BH, w.dgp, 4ll * BH, B,
-                               H, (float*)nullptr);
+                               H, (float*)nullptr, (unsigned*)nullptr);
             if (st > 0 || dh0 != nullptr) hipLaunchKernelGGL((lstm_step_kernel<false, 3>), grid, dim3(256), 0, s, a);
         }
     }
@@ -739,8 +747,9 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
     const int TB = T * B;
     if (int rc = colsum(w.dG, TB, 4 * H, 4 * H, w.cs, db, s)) return rc;
     // the gate gradients are the A operand of every product below: their maxima (two-plane fp16 mode) are taken once
+    // (the fp16 recurrence has collected them step by step; otherwise one pass over dG)
     const bool dg_maxima = g_matrix_mode == GTG_MATRIX_F16X2;
-    if (dg_maxima)
+    if (dg_maxima && !f16)
         if (int rc = absmax_partials(w.dG, TB, 4ll * H, 4ll * H, w.absmax, s)) return rc;
     GemmDesc g;
     // dW_ih = dG^T X
