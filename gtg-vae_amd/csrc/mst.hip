@@ -72,7 +72,8 @@ __device__ __forceinline__ float wave_max_uniform(float v)
 extern "C" __device__ int gtg_llvm_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 __device__ __forceinline__ float mark_lane_nan(float w, int lane)
 {
-    return __int_as_float(gtg_llvm_writelane(0x7fc00000, lane, __float_as_int(w)));
+    // (all ones: a quiet NaN that is an inline constant, so the lane index needs no detour through M0)
+    return __int_as_float(gtg_llvm_writelane(-1, lane, __float_as_int(w)));
 }
 
 // Asynchronous global -> LDS copy of one upper-triangular row (m_tri floats)
@@ -237,9 +238,11 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
 #define GTG_MST_VISIT(m_)                                                    \
         {                                                                        \
             const int mm = (m_);                                                 \
-            float tl = lo[mm & 31], th = hi[mm & 31];                            \
-            asm volatile("" : "+v"(tl), "+v"(th));                               \
-            const float t = (mm < 32) ? tl : th;                                 \
+            float t;                                                             \
+            asm volatile("s_set_gpr_idx_on %3, gpr_idx(SRC0)\n\t"                  \
+                         "v_mov_b32 %0, v0\n\t"                                   \
+                         "s_set_gpr_idx_off"                                     \
+                         : "=v"(t) : "{v[0:31]}"(lo), "{v[32:63]}"(hi), "s"(mm)); \
             w = mark_lane_nan(w, mm);                                            \
             const bool upd = (t != 0.f) && (t > w);                              \
             w = upd ? t : w;                                                     \
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
         for (int round = 1; round < V - 1; ++round) {
             const float mx = wave_max_uniform(w);
             const unsigned long long eq = __ballot(w == mx);
-            const int first = __ffsll((long long)eq) - 1;
+            // (never empty: a round starts with at least two unvisited present vertices, whose weights are numbers)
+            const int first = __builtin_ctzll(eq);
             // nothing reached yet -> Python's index -1 = the last present vertex
             const int m = __builtin_amdgcn_readfirstlane(
                 (__float_as_int(mx) == __float_as_int(NEG_SENTINEL)) ? last : first);
