@@ -233,8 +233,11 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
         float w = pj ? NEG_SENTINEL : __builtin_nanf("");
         int parent = root;
         // One round: visit m, then let column m improve every unvisited vertex.
-        // Row element m is fetched from both register halves with one indexed
-        // move each and selected by a scalar condition (no branch).
+        // Row element m comes from ONE indexed move: the asm statement asks for the two register halves of the
+        // row in v[0:31] and v[32:63] (physical-register constraints, which the register allocator honours by
+        // keeping the row there for the whole loop), so the 64 elements are consecutive registers and index m
+        // (0..63) from v0 reaches all of them -- where an indexed move per half and a select would take three
+        // vector and three scalar instructions.
 #define GTG_MST_VISIT(m_)                                                    \
         {                                                                        \
             const int mm = (m_);                                                 \
