@@ -252,16 +252,25 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
             parent = upd ? mm : parent;                                          \
         }
         if (V > 1) GTG_MST_VISIT(root)  // round 0: weights[root] = +maxsize wins
-        for (int round = 1; round < V - 1; ++round) {
-            const float mx = wave_max_uniform(w);
-            const unsigned long long eq = __ballot(w == mx);
-            // (never empty: a round starts with at least two unvisited present vertices, whose weights are numbers)
-            const int first = __builtin_ctzll(eq);
-            // nothing reached yet -> Python's index -1 = the last present vertex
-            const int m = __builtin_amdgcn_readfirstlane(
-                (__float_as_int(mx) == __float_as_int(NEG_SENTINEL)) ? last : first);
-            GTG_MST_VISIT(m)
+        // (eq is never empty: a round starts with at least two unvisited present vertices, whose weights are
+        // numbers; nothing reached yet -> Python's index -1 = the last present vertex)
+#define GTG_MST_ROUND()                                                                      \
+        {                                                                                        \
+            const float mx = wave_max_uniform(w);                                                \
+            const unsigned long long eq = __ballot(w == mx);                                     \
+            const int first = __builtin_ctzll(eq);                                               \
+            const int m = __builtin_amdgcn_readfirstlane(                                        \
+                (__float_as_int(mx) == __float_as_int(NEG_SENTINEL)) ? last : first);            \
+            GTG_MST_VISIT(m)                                                                     \
         }
+        // two rounds per trip: the loop's own counter, compare and branch are a tenth of a round's instructions
+        int round = 1;
+        for (; round + 1 < V - 1; round += 2) {
+            GTG_MST_ROUND()
+            GTG_MST_ROUND()
+        }
+        if (round < V - 1) GTG_MST_ROUND()
+#undef GTG_MST_ROUND
 #undef GTG_MST_VISIT
 
         // ---- ordered output: slot (local index - 1) <- (parent, vertex) -----
