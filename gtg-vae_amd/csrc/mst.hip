@@ -112,7 +112,10 @@ __device__ __forceinline__ void stage_row_async(const float* __restrict__ row, f
 // Persistent: every wave walks graphs g = wave id, wave id + #waves, ...  For
 // upper-triangular input the next graph's row is already in flight (LDS-DMA)
 // while the current graph's spanning tree is computed from registers.
-template <bool TRIU, bool N64>
+// PIN: the row's 64 registers are pinned to v0..v63 for the one-move fetch of the Prim round (see GTG_MST_VISIT).
+// Under that constraint the compiler builds the generic triangular fill with about twice the scalar
+// instructions, which a graph of few nodes (few rounds) does not earn back: the launcher pins from 40 nodes on.
+template <bool TRIU, bool N64, bool PIN>
 __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const float* __restrict__ in, int64_t G, int n,
                                                          int32_t* __restrict__ edges, int32_t* __restrict__ count)
 {
@@ -242,10 +245,16 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
         {                                                                        \
             const int mm = (m_);                                                 \
             float t;                                                             \
-            asm volatile("s_set_gpr_idx_on %3, gpr_idx(SRC0)\n\t"                  \
-                         "v_mov_b32 %0, v0\n\t"                                   \
-                         "s_set_gpr_idx_off"                                     \
-                         : "=v"(t) : "{v[0:31]}"(lo), "{v[32:63]}"(hi), "s"(mm)); \
+            if constexpr (PIN) {                                                 \
+                asm volatile("s_set_gpr_idx_on %3, gpr_idx(SRC0)\n\t"              \
+                             "v_mov_b32 %0, v0\n\t"                               \
+                             "s_set_gpr_idx_off"                                 \
+                             : "=v"(t) : "{v[0:31]}"(lo), "{v[32:63]}"(hi), "s"(mm)); \
+            } else {                                                             \
+                float tl = lo[mm & 31], th = hi[mm & 31];                        \
+                asm volatile("" : "+v"(tl), "+v"(th));                           \
+                t = (mm < 32) ? tl : th;                                         \
+            }                                                                    \
             w = mark_lane_nan(w, mm);                                            \
             const bool upd = (t != 0.f) && (t > w);                              \
             w = upd ? t : w;                                                     \
@@ -316,11 +325,13 @@ static int mst_launch(bool triu, const float* in, int64_t G, int n, int32_t* edg
     if (blocks > resident) blocks = resident;
     ProfScope prof(s, triu ? "mst_triu" : "mst_full", G, n, 0);
     if (triu && n == 64)
-        hipLaunchKernelGGL((mst_kernel<true, true>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+        hipLaunchKernelGGL((mst_kernel<true, true, true>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+    else if (triu && n >= 40)
+        hipLaunchKernelGGL((mst_kernel<true, false, true>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
     else if (triu)
-        hipLaunchKernelGGL((mst_kernel<true, false>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+        hipLaunchKernelGGL((mst_kernel<true, false, false>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
     else
-        hipLaunchKernelGGL((mst_kernel<false, false>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+        hipLaunchKernelGGL((mst_kernel<false, false, true>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
     return check_launch("mst_kernel");
 }
 
