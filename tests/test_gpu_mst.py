@@ -82,6 +82,26 @@ def test_random_batches_match_c_oracle(n):
     assert np.array_equal(c, wc) and np.array_equal(e, we)
 
 
+@pytest.mark.parametrize("n", [64, 48, 12])
+def test_rows_that_are_not_16_byte_aligned(n):
+    """A row pointer off the 16-byte grid takes the dword staging path of the kernel (the aligned one
+    copies 16-byte pieces): same edge lists."""
+    from oracle import c_mst
+    from gtg_vae_amd import mst_graph_batched
+
+    rng = np.random.default_rng(n)
+    G, m = 300, n * (n + 1) // 2
+    rows = rng.uniform(0, 1, size=(G, m)).astype(np.float32)
+    rows[rng.uniform(size=rows.shape) < 0.15] = 0.0
+    we, wc = c_mst.mst_triu(rows, n)
+    buf = torch.empty(G * m + 1, dtype=torch.float32, device="cuda")
+    view = buf[1:].view(G, m)
+    view.copy_(torch.from_numpy(rows))
+    assert view.data_ptr() % 16 == 4
+    e, c = mst_graph_batched(view, n)
+    assert np.array_equal(c.cpu().numpy(), wc) and np.array_equal(e.cpu().numpy(), we)
+
+
 def test_extreme_values_match_oracle():
     from oracle import c_mst
 
