@@ -393,11 +393,13 @@ __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* 
         __syncthreads();  // Y complete; Hs free for the next item
         const float g = p.g;
         const float* yrow = Yc + p.am * DW_LD;
-        fetch(p, it + 2);
         if (wave_live) {
 #pragma unroll
             for (int k = 0; k < DW_COLS; ++k) acc[k] = fmaf(g, yrow[k], acc[k]);
         }
+        // (after the accumulation, not before it: the item's sixteen row / adjacency registers are then free
+        // while the 64 LDS reads above run, so several of them can be in flight instead of one at a time)
+        fetch(p, it + 2);
     };
     Item p0, p1;
     if (items > 0) {
