@@ -1188,42 +1188,57 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         for (int q = 0; q < 4; ++q)
             if (gcol + q < a.N) ib[q] = a.inv_b_rows[gcol + q];
     }
+    // PREC 5: the inverse scales of this lane's rows, all fetched before the store loop (inside it every row
+    // would wait for its own load)
+    float ia[NIT];
+    if constexpr (PREC == 5) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) ia[it] = a.inv_a_rows[max(min(m0 + wm + it * RPI + rsub, Mr - 1), 0)];
+    }
     f32x4 colacc = {0.f, 0.f, 0.f, 0.f};  // this lane's share of the column sums of the stored values
+    // The store loop is instantiated once per epilogue and chosen by ONE switch: with the switch inside the
+    // loop the compiler keeps it there, a chain of scalar compares and branches per element.
+    auto store_rows = [&](auto epi_tag) {
+        constexpr int E = decltype(epi_tag)::value;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int lrow = it * RPI + rsub;
-        const int grow = m0 + wm + lrow;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&sC[lrow * LDC + c4 * 4]);
+        for (int it = 0; it < NIT; ++it) {
+            const int lrow = it * RPI + rsub;
+            const int grow = m0 + wm + lrow;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&sC[lrow * LDC + c4 * 4]);
 #pragma unroll
-        for (int g = 1; g < KG; ++g) v += *reinterpret_cast<const f32x4*>(&sC[g * GW * WTM * LDC + lrow * LDC + c4 * 4]);
-        if (grow >= Mr || gcol >= a.N) continue;
-        if constexpr (PREC == 5) {
-            // undo the operands' row scales (powers of two: exact)
-            const float ia = a.inv_a_rows[grow];
+            for (int g = 1; g < KG; ++g) v += *reinterpret_cast<const f32x4*>(&sC[g * GW * WTM * LDC + lrow * LDC + c4 * 4]);
+            if (grow >= Mr || gcol >= a.N) continue;
+            if constexpr (PREC == 5) {
+                // undo the operands' row scales (powers of two: exact)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = (v[q] * ia) * ib[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float y = v[q] + bv[q];
-            switch (epi) {
-                case EPI_RELU: y = fmaxf(y, 0.f); break;
-                case EPI_SIGMOID: y = 1.f / (1.f + expf(-y)); break;
-                case EPI_MASK: y = (xv[it][q] > 0.f) ? y : 0.f; break;
-                case EPI_ACCUM: y += xv[it][q]; break;
-                default: break;
+                for (int q = 0; q < 4; ++q) v[q] = (v[q] * ia[it]) * ib[q];
             }
-            v[q] = y;
-        }
-        colacc += v;
-        float* dst = C + (long long)grow * ldc + gcol;
-        if (vec_ok) {
-            *reinterpret_cast<f32x4*>(dst) = v;
-        } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (gcol + q < a.N) dst[q] = v[q];
+            for (int q = 0; q < 4; ++q) {
+                float y = v[q] + bv[q];
+                if constexpr (E == EPI_RELU) y = fmaxf(y, 0.f);
+                if constexpr (E == EPI_SIGMOID) y = 1.f / (1.f + expf(-y));
+                if constexpr (E == EPI_MASK) y = (xv[it][q] > 0.f) ? y : 0.f;
+                if constexpr (E == EPI_ACCUM) y += xv[it][q];
+                v[q] = y;
+            }
+            colacc += v;
+            float* dst = C + (long long)grow * ldc + gcol;
+            if (vec_ok) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (gcol + q < a.N) dst[q] = v[q];
+            }
         }
+    };
+    switch (epi) {
+        case EPI_RELU: store_rows(std::integral_constant<int, EPI_RELU>{}); break;
+        case EPI_SIGMOID: store_rows(std::integral_constant<int, EPI_SIGMOID>{}); break;
+        case EPI_MASK: store_rows(std::integral_constant<int, EPI_MASK>{}); break;
+        case EPI_ACCUM: store_rows(std::integral_constant<int, EPI_ACCUM>{}); break;
+        default: store_rows(std::integral_constant<int, EPI_STORE>{}); break;
     }
     // Column sums of what this wave stored (its WTM rows x WTN columns), rows in a fixed order: a bias
     // gradient then needs no pass of its own over C, only the sum of these per-row-block partials.
