@@ -50,7 +50,8 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_sparse_kernel(const float* _
     __shared__ __attribute__((aligned(16))) float Wt[64 * C1_LD];  // Wt[k][c] = W1[c0 + c][k]
     __shared__ float smax[2][C1_THREADS / 64];
     float amax = 0.f;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in a scalar register: row indices stay scalar
     const int slab = blockIdx.x % slabs, chunk = blockIdx.x / slabs, chunks = gridDim.x / slabs;
     const int c0 = slab * C1_COLS;
     int rows = rows_max;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(256) void pool_sparse_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float T[64 * PS_COLS];
     __shared__ float wv[4][PS_COLS];
     __shared__ int wi[4][PS_COLS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in a scalar register: row indices stay scalar
     const int b = blockIdx.y, c0 = blockIdx.x * PS_COLS;
     const int nb = meta[b], off = meta[B + b], R = meta[2 * B];
 

@@ -534,7 +534,9 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
     float* const sA1 = sA0 + TA::SIZE + TB::SIZE;
     float* const sB1 = sA1 + TA::SIZE;
 
-    const int lane = tid & 63, wave = tid >> 6;
+    // (the wave index in a scalar register: what depends on it alone -- tile offsets, the operand a wave stages --
+    // is then scalar arithmetic and scalar branches instead of per-lane selects)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = (wave / WAVES_N) * WTM, wn = (wave % WAVES_N) * WTN;
 
