@@ -634,16 +634,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4_t& p0, u32x4_t
 // x[0..7] * scale -> the eight fp16 of the value rounded to nearest and of what is left, rounded to nearest
 __device__ __forceinline__ void split8h(const float (&x)[8], float scale, u32x4_t& p0, u32x4_t& p1)
 {
-    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float a0 = x[2 * q] * scale, b0 = x[2 * q + 1] * scale;
-        const f16x2_t hi = {(_Float16)a0, (_Float16)b0};
-        a0 -= (float)hi[0];
-        b0 -= (float)hi[1];
-        const f16x2_t lo = {(_Float16)a0, (_Float16)b0};
-        p0[q] = __builtin_bit_cast(unsigned, hi);
-        p1[q] = __builtin_bit_cast(unsigned, lo);
+        unsigned hi, lo;
+        split_pair_f16(x[2 * q], x[2 * q + 1], scale, hi, lo);
+        p0[q] = hi;
+        p1[q] = lo;
     }
 }
 

@@ -117,6 +117,25 @@ __device__ __forceinline__ void f16x2_scale(float mx, float& scale, float& inver
     scale = __uint_as_float((unsigned)(267 - e) << 23);    // 2^(13 - (e - 127))
     inverse = __uint_as_float((unsigned)(e - 13) << 23);   // 2^((e - 127) - 13)
 }
+// The two fp16 planes of the pair (x0, x1) * scale in four instructions: w0 = the products rounded to fp16
+// (low half x0, high half x1), w1 = what is left of them, rounded.  v_fma_mix* multiplies in fp32, adds an
+// fp16 or fp32 operand and rounds once to fp16, into one half of the destination: the product x * scale is
+// exact (a power of two), so w0 is its fp16 rounding and x * scale - w0, exact in fp32, is rounded once for
+// w1 -- the same values as scaling, converting, converting back, subtracting and converting again, which
+// the compiler builds from seven instructions per pair (it converts the first plane twice, once packed for
+// the store and once per element as the subtrahend).
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, float scale, unsigned& w0, unsigned& w1)
+{
+    unsigned a, b;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(a), "=&v"(b)
+        : "v"(x0), "v"(x1), "v"(scale));
+    w0 = a;
+    w1 = b;
+}
 #endif
 inline int gemm_colsum_rows(int M) { return 2 * ((M + 127) / 128); }
 

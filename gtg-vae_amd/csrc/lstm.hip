@@ -102,13 +102,10 @@ __device__ __forceinline__ void store_planes4h(__bf16* img, long long plane, int
     u32x2 p0, p1;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        float a0 = x[2 * q] * scale, b0 = x[2 * q + 1] * scale;
-        const f16x2 hi = {(_Float16)a0, (_Float16)b0};
-        a0 -= (float)hi[0];
-        b0 -= (float)hi[1];
-        const f16x2 lo = {(_Float16)a0, (_Float16)b0};
-        p0[q] = __builtin_bit_cast(unsigned, hi);
-        p1[q] = __builtin_bit_cast(unsigned, lo);
+        unsigned hi, lo;
+        split_pair_f16(x[2 * q], x[2 * q + 1], scale, hi, lo);
+        p0[q] = hi;
+        p1[q] = lo;
     }
     __bf16* dst = img + ((long long)(k0 >> 4) * rows + row) * 16 + (k0 & 15);
     *reinterpret_cast<u32x2*>(dst) = p0;
