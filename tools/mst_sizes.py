@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Time the batched MST read-out at several graph sizes (65 536 random triangular rows of 10 / 32 / 48 / 64 nodes,
+8 192 full matrices of each size): mst_sizes.py [library]  (an experimental build of the library for A/B runs)."""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 from gtg_vae_amd import _lib
