@@ -206,12 +206,29 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
 #pragma unroll
         for (int d = 0; d < LDEPTH - 1; ++d) load(d, f[d]);
         int j = 0;
+        // One sub-step: fetch the set that was multiplied last, multiply the oldest one.  (The scheduler must
+        // not move the loads down among the MFMAs: left to itself it issued the loads a set needs right before
+        // the loop's back edge.)
+        auto substep = [&](int jj, int u) {
+            load(jj + LDEPTH - 1 + u, f[(LDEPTH - 1 + u) % LDEPTH]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f[u]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (mine == 4 * LDEPTH) {
+            // the common depth (hidden size 1024: 64 k blocks over four waves) as straight-line code: at a loop
+            // header the compiler waits for EVERY load in flight, the set just requested included, which
+            // exposes a full memory latency per trip; without the loop it counts the loads and waits for the
+            // oldest set only
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < LDEPTH; ++u) substep(t * LDEPTH, u);
+            j = 4 * LDEPTH;
+        }
         for (; j + LDEPTH - 1 < mine; j += LDEPTH) {
 #pragma unroll
-            for (int u = 0; u < LDEPTH; ++u) {
-                load(j + LDEPTH - 1 + u, f[(LDEPTH - 1 + u) % LDEPTH]);
-                mma(f[u]);
-            }
+            for (int u = 0; u < LDEPTH; ++u) substep(j, u);
         }
         // at most LDEPTH - 1 blocks are left, and they are the ones sets 0 .. LDEPTH - 2 hold
 #pragma unroll
