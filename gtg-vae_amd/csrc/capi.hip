@@ -484,7 +484,7 @@ int gtg_encoder_compact_fwd(const float* adj, const int32_t* extents, const floa
 }
 
 struct EncCBwdWs {
-    float *dT2c, *dZ1c, *pg, *cs, *slabs, *tail, *dw2;
+    float *dT2c, *dZ1c, *pg, *cs, *slabs, *tail, *dw2, *dw1;
     float* proto_rows;   // plane path: the prototype rows' gradient as fp32
     void* w2t_planes;    // plane path: W2^T as k-blocked bf16 planes
     float *inv_rows, *inv_w;  // fp16 planes: inverse row scales of dT2c (rows) and of W2^T (H)
@@ -510,6 +510,8 @@ static void enc_cbwd_layout(Carver& c, int64_t B, int n, int d, EncCBwdWs* w)
         c.take<char>(max2(gemm_splitk_workspace(d, H, (int)rows, 1), gemm_splitk_workspace(H, n, (int)rows, 1))));
     // the sparse dW2 kernel's partials
     w->dw2 = reinterpret_cast<float*>(c.take<char>(dw2_sparse_applies(B, n, d, H) ? dw2_sparse_workspace(d, H) : 0));
+    // the sparse dW1 kernel's partials
+    w->dw1 = reinterpret_cast<float*>(c.take<char>(dw1_sparse_applies((int64_t)rows, n, H) ? dw1_sparse_workspace(H) : 0));
     size_t tb, cb;
     gemm_tail_workspace(&tb, &cb);
     w->tail = reinterpret_cast<float*>(c.take<char>(tb));
@@ -594,7 +596,9 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
         GTG_TRY(colsum_parts_and_short(w.cs, gemm_colsum_rows(rows), all_rows, H, db1, dpooled, B, d, d, db2, nullptr, s));
     else
         GTG_TRY(colsum_dev_and_short(w.dZ1c, rows, all_rows, H, H, w.cs, db1, dpooled, B, d, d, db2, s));
-    // dW1[c][i] = sum over stored rows dZ1c[r][c] * adjc[r][i]   (prototype rows carry unit adjacency rows)
+    // dW1[c][i] = sum over stored rows dZ1c[r][c] * adjc[r][i]   (prototype rows carry unit adjacency rows):
+    // through the nonzeros of the adjacency rows where the shape allows, else as the dense product
+    if (dw1_sparse_applies(rows, n, H)) return dw1_sparse(adjc, n, w.dZ1c, H, all_rows, rows, w.dw1, dW1, s);
     g = GemmDesc();
     g.A = w.dZ1c; g.lda = H; g.a_kc = false;
     g.B = adjc; g.ldb = n; g.b_kc = false;

@@ -21,6 +21,7 @@ namespace gtg {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 // v where keep, +0 elsewhere, as a bit mask: written as a select the compiler moves the load that feeds
 // it back under a branch
@@ -423,8 +424,10 @@ __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* 
 
 // dW2[c][h] = sum over groups of partial[group][h][c], groups in order; 32 x 32 tiles transposed through LDS so
 // that reads and writes are both whole 128-byte rows.
+// (h_valid <= H columns of each output row are stored, ld_out apart: the first layer's gradient keeps 64 rows
+// of partials whatever n is.)
 __global__ __launch_bounds__(256) void dw2_reduce_kernel(const float* __restrict__ partial, int d, int H,
-                                                         float* __restrict__ out)
+                                                         float* __restrict__ out, int ld_out, int h_valid)
 {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -447,7 +450,120 @@ __global__ __launch_bounds__(256) void dw2_reduce_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, h = h0 + tx;
-        if (c < d && h < H) out[(long long)c * H + h] = tile[tx][ty + 8 * i];
+        if (c < d && h < h_valid) out[(long long)c * ld_out + h] = tile[tx][ty + 8 * i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dW1 through the adjacency's sparsity.  With identity node features the first layer is Z1 = A W1^T + b1, so
+//   dW1[c][i] = sum over stored rows r of dZ1c[r][c] * adjc[r][i]
+// and a row of adjc has deg + 1 nonzeros out of n <= 64: the dense product multiplies mostly zeros and is
+// bound by its one pass over dZ1c.  Here that pass is all there is.  A block owns 64 columns c (one per lane) and a
+// chunk of the stored rows; each of its eight waves takes every eighth row of the chunk: the lane loads
+// dZ1c[r][c] (one 256-byte run per wave) and, as lane k, adjc[r][k]; a ballot gives the nonzero columns and the
+// wave walks them with a scalar loop (v_readlane for the coefficient), adding coefficient * dZ1c[r][c] to the
+// accumulator of column i -- 64 accumulators per lane, indexed by a scalar.  D1_UNROLL rows are in flight per
+// wave, the next batch requested before the current one is walked.  The eight waves' accumulators are added in
+// a fixed order through LDS and the block stores partial[chunk][i][c] (c along the lanes: 256-byte runs);
+// dw2_reduce_kernel adds the chunks in order and transposes: reproducible.
+// ---------------------------------------------------------------------------
+constexpr int D1_THREADS = 512;
+constexpr int D1_WAVES = D1_THREADS / 64;
+constexpr int D1_UNROLL = 8;
+constexpr int D1_CHUNKS = DW_GROUPS;  // the reduce kernel adds DW_GROUPS partials
+
+__global__ __launch_bounds__(D1_THREADS, 4) void dw1_sparse_kernel(const float* __restrict__ adjc, int n,
+                                                                const float* __restrict__ dz, int ldz,
+                                                                const int* __restrict__ rows_dev, int rows_max,
+                                                                float* __restrict__ partial)
+{
+    __shared__ float red[D1_WAVES / 2][64][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rows = min(rows_dev[0], rows_max);
+    const int per = (rows + D1_CHUNKS - 1) / D1_CHUNKS;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    const float* const zc = dz + blockIdx.x * 64 + lane;
+    const float* const ac = adjc + min(lane, n - 1);
+    const bool lane_ok = lane < n;
+
+    // The 64 accumulators sit in v[0:63] (physical-register constraints on the statement that updates them), so
+    // one scalar index reaches all of them; as a plain array the compiler keeps half of them in scratch memory.
+    f32x32 lo, hi;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) lo[k] = hi[k] = 0.f;
+
+    struct Batch {
+        float x[D1_UNROLL], a[D1_UNROLL];
+    };
+    // (clamped rows instead of a branch around the loads: a row past the chunk is read again with zero
+    // coefficients, and the loads of a batch are all issued together)
+    auto fetch = [&](Batch& b, int r) {
+#pragma unroll
+        for (int u = 0; u < D1_UNROLL; ++u) {
+            const int rr = r + D1_WAVES * u;
+            const int rc = max(min(rr, r1 - 1), 0);
+            b.x[u] = zc[rc * ldz];  // 32-bit offsets: rows * ldz < 2^31 is checked on the host
+            b.a[u] = keep_if(ac[rc * n], lane_ok && rr < r1);
+        }
+    };
+    auto walk = [&](const Batch& b) {
+#pragma unroll
+        for (int u = 0; u < D1_UNROLL; ++u) {
+            unsigned long long mask = __ballot(b.a[u] != 0.f);
+            while (mask) {
+                const int k = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b.a[u]), k));
+                // v[k] += ak * x: the index applies to the accumulator as source and as destination, not to
+                // the scalar coefficient nor to x (SRC1 is not indexed)
+                asm volatile("s_set_gpr_idx_on %3, gpr_idx(SRC2,DST)\n\t"
+                             "v_fma_f32 v0, %2, %4, v0\n\t"
+                             "s_set_gpr_idx_off"
+                             : "+{v[0:31]}"(lo), "+{v[32:63]}"(hi)
+                             : "s"(ak), "s"(k), "v"(b.x[u]));
+            }
+        }
+    };
+    Batch b0, b1;
+    constexpr int STEP = D1_WAVES * D1_UNROLL;
+    int r = r0 + wave;
+    if (r0 < r1) {
+        fetch(b0, r);
+        for (; r < r1; r += 2 * STEP) {
+            fetch(b1, r + STEP);
+            walk(b0);
+            fetch(b0, r + 2 * STEP);
+            walk(b1);
+        }
+    }
+    // waves 4..7 -> 0..3, 2..3 -> 0..1, 1 -> 0
+#pragma unroll
+    for (int half = D1_WAVES / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                red[wave - half][k][lane] = lo[k];
+                red[wave - half][k + 32][lane] = hi[k];
+            }
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                lo[k] += red[wave][k][lane];
+                hi[k] += red[wave][k + 32][lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float* dst = partial + (long long)blockIdx.y * 64 * ldz + blockIdx.x * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            dst[k * ldz] = lo[k];
+            dst[(k + 32) * ldz] = hi[k];
+        }
     }
 }
 
@@ -498,7 +614,28 @@ int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, co
     hipLaunchKernelGGL(dw2_sparse_kernel, dim3(H / DW_COLS, DW_GROUPS, (d + DW_CPB - 1) / DW_CPB), dim3(DW_THREADS), 0, s,
                        adj, h1c, H, dpool, argmax, meta, dT2c, proto_rows, (int)B, n, d, partial);
     if (int rc = check_launch("dw2_sparse_kernel")) return rc;
-    hipLaunchKernelGGL(dw2_reduce_kernel, dim3((d + 31) / 32, (H + 31) / 32), dim3(256), 0, s, partial, d, H, dW2);
+    hipLaunchKernelGGL(dw2_reduce_kernel, dim3((d + 31) / 32, (H + 31) / 32), dim3(256), 0, s, partial, d, H, dW2, H, H);
+    return check_launch("dw2_reduce_kernel");
+}
+
+bool dw1_sparse_applies(int64_t rows, int n, int H)
+{
+    // small problems are launch-bound either way and keep the dense product
+    return n >= 1 && n <= 64 && (H % 64) == 0 && rows >= 2048 && rows * (int64_t)H < (1ll << 31);
+}
+
+size_t dw1_sparse_workspace(int H) { return (size_t)D1_CHUNKS * 64 * H * sizeof(float); }
+
+int dw1_sparse(const float* adjc, int n, const float* dZ1c, int H, const int* rows_dev, int64_t rows_max, float* partial,
+               float* dW1, hipStream_t s)
+{
+    if (!dw1_sparse_applies(rows_max, n, H)) return set_error(GTG_ERR_INVALID, "dw1_sparse: shape not supported");
+    ProfScope prof(s, "dw1_sparse", rows_max, H, n);
+    hipLaunchKernelGGL(dw1_sparse_kernel, dim3(H / 64, D1_CHUNKS), dim3(D1_THREADS), 0, s, adjc, n, dZ1c, H, rows_dev,
+                       (int)rows_max, partial);
+    if (int rc = check_launch("dw1_sparse_kernel")) return rc;
+    // partial[chunk][i][c] -> dW1[c][i]
+    hipLaunchKernelGGL(dw2_reduce_kernel, dim3((H + 31) / 32, 2), dim3(256), 0, s, partial, H, 64, dW1, n, n);
     return check_launch("dw2_reduce_kernel");
 }
 

@@ -257,6 +257,12 @@ size_t dw2_sparse_workspace(int d, int H);
 int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, const int32_t* argmax, const int32_t* meta,
                const float* dT2c, const float* proto_rows, int64_t B, int n, int d, float* partial, float* dW2,
                hipStream_t s);
+// dW1[c][i] = sum over the stored rows (count read on the device) of dZ1c[r][c] * adjc[r][i], walking the nonzeros
+// of each adjacency row (gcn_sparse.hip).  partial: dw1_sparse_workspace() bytes.
+bool dw1_sparse_applies(int64_t rows, int n, int H);
+size_t dw1_sparse_workspace(int H);
+int dw1_sparse(const float* adjc, int n, const float* dZ1c, int H, const int* rows_dev, int64_t rows_max, float* partial,
+               float* dW1, hipStream_t s);
 int pool_sparse(const float* adj, const float* t2c, const int32_t* meta, const float* b2, int64_t B, int n, int d,
                 float* pooled, int32_t* argmax, hipStream_t s);
 

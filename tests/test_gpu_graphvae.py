@@ -157,7 +157,9 @@ def test_conv2_weight_gradient_through_the_pool_routing(B, N, d):
     (one aggregated row of H1 per graph and column) instead of the dense product: awkward graphs
     cycled through the batch (empty, one edge, high indices only, chain, self loops, multi-edges,
     complete, random), a batch that is not a multiple of the 16 graph groups, a width whose last
-    wave of pooled columns is partly idle (288); all four gradients against the oracle."""
+    wave of pooled columns is partly idle (288); all four gradients against the oracle.  At these
+    sizes (2048 stored rows or more, hidden width a multiple of 64) conv1's weight gradient is
+    taken through the nonzeros of the adjacency rows as well: n = 64, 10 and 33 columns."""
     from gtg_vae_amd import functional as Fn
     from oracle import graphvae_oracle as O
 
