@@ -458,8 +458,8 @@ __global__ __launch_bounds__(256) void dw2_reduce_kernel(const float* __restrict
 // dW1 through the adjacency's sparsity.  With identity node features the first layer is Z1 = A W1^T + b1, so
 //   dW1[c][i] = sum over stored rows r of dZ1c[r][c] * adjc[r][i]
 // and a row of adjc has deg + 1 nonzeros out of n <= 64: the dense product multiplies mostly zeros and is
-// bound by its one pass over dZ1c.  Here that pass is all there is.  A block owns 64 columns c (one per lane) and a
-// chunk of the stored rows; each of its eight waves takes every eighth row of the chunk: the lane loads
+// bound by its one pass over dZ1c.  Here that pass is all there is.  A block owns 64 columns c (one per lane; or
+// 128, two per lane) and a chunk of the stored rows; each of its eight waves takes every eighth row of the chunk: the lane loads
 // dZ1c[r][c] (one 256-byte run per wave) and, as lane k, adjc[r][k]; a ballot gives the nonzero columns and the
 // wave walks them with a scalar loop (v_readlane for the coefficient), adding coefficient * dZ1c[r][c] to the
 // accumulator of column i -- 64 accumulators per lane, indexed by a scalar.  D1_UNROLL rows are in flight per
@@ -472,29 +472,39 @@ constexpr int D1_WAVES = D1_THREADS / 64;
 constexpr int D1_UNROLL = 8;
 constexpr int D1_CHUNKS = DW_GROUPS;  // the reduce kernel adds DW_GROUPS partials
 
-__global__ __launch_bounds__(D1_THREADS, 4) void dw1_sparse_kernel(const float* __restrict__ adjc, int n,
-                                                                const float* __restrict__ dz, int ldz,
-                                                                const int* __restrict__ rows_dev, int rows_max,
-                                                                float* __restrict__ partial)
+// NC columns per lane (1 or 2).  The walk is bound by the scalar instructions it issues per nonzero (find-first,
+// clear, compare, branch, index on / off), so two columns per lane -- one 8-byte load, two multiply-adds under one
+// index -- halve them per byte; the block then owns 128 columns and its 128 accumulators per lane leave
+// room for two waves per SIMD, each of which issues at its own pace: 29.0 us against 32.0 us for one column per
+// lane and four waves per SIMD at 512 graphs of 64 nodes, 2d = 1024 (the dense product: 41 us + 5 us).
+template <int NC>
+__global__ __launch_bounds__(D1_THREADS, NC == 1 ? 4 : 2) void dw1_sparse_kernel(const float* __restrict__ adjc, int n,
+                                                                             const float* __restrict__ dz, int ldz,
+                                                                             const int* __restrict__ rows_dev,
+                                                                             int rows_max, float* __restrict__ partial)
 {
-    __shared__ float red[D1_WAVES / 2][64][64];
+    typedef float xvec __attribute__((ext_vector_type(NC)));
+    __shared__ float red[D1_WAVES / 2][64][64 * NC];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows = min(rows_dev[0], rows_max);
     const int per = (rows + D1_CHUNKS - 1) / D1_CHUNKS;
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-    const float* const zc = dz + blockIdx.x * 64 + lane;
+    const int col = blockIdx.x * 64 * NC + lane * NC;
+    const float* const zc = dz + col;
     const float* const ac = adjc + min(lane, n - 1);
-    const bool lane_ok = lane < n;
+    const unsigned long long lanes_n = n >= 64 ? ~0ull : (1ull << n) - 1;
 
-    // The 64 accumulators sit in v[0:63] (physical-register constraints on the statement that updates them), so
-    // one scalar index reaches all of them; as a plain array the compiler keeps half of them in scratch memory.
-    f32x32 lo, hi;
+    // The accumulators of the lane's first column sit in v[0:63] and those of its second in v[64:127]
+    // (physical-register constraints on the statement that updates them), so one scalar index reaches all of
+    // them; as plain arrays the compiler keeps half of them in scratch memory.
+    f32x32 lo0, hi0, lo1, hi1;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) lo[k] = hi[k] = 0.f;
+    for (int k = 0; k < 32; ++k) lo0[k] = hi0[k] = lo1[k] = hi1[k] = 0.f;
 
     struct Batch {
-        float x[D1_UNROLL], a[D1_UNROLL];
+        xvec x[D1_UNROLL];
+        float a[D1_UNROLL];
     };
     // (clamped rows instead of a branch around the loads: a row past the chunk is read again with zero
     // coefficients, and the loads of a batch are all issued together)
@@ -503,66 +513,102 @@ __global__ __launch_bounds__(D1_THREADS, 4) void dw1_sparse_kernel(const float* 
         for (int u = 0; u < D1_UNROLL; ++u) {
             const int rr = r + D1_WAVES * u;
             const int rc = max(min(rr, r1 - 1), 0);
-            b.x[u] = zc[rc * ldz];  // 32-bit offsets: rows * ldz < 2^31 is checked on the host
-            b.a[u] = keep_if(ac[rc * n], lane_ok && rr < r1);
+            // 32-bit offsets: rows * ldz < 2^31 is checked on the host
+            b.x[u] = *reinterpret_cast<const xvec*>(zc + rc * ldz);
+            b.a[u] = ac[rc * n];
         }
     };
-    auto walk = [&](const Batch& b) {
+    // (the rows past the chunk and the lanes past n are taken out of the ballot, not out of the loaded value: a
+    // select on the value makes the compiler branch around the load and wait for it on the spot)
+    auto walk = [&](const Batch& b, int r) {
 #pragma unroll
         for (int u = 0; u < D1_UNROLL; ++u) {
-            unsigned long long mask = __ballot(b.a[u] != 0.f);
+            unsigned long long mask = __ballot(b.a[u] != 0.f) & (r + D1_WAVES * u < r1 ? lanes_n : 0ull);
             while (mask) {
                 const int k = __builtin_ctzll(mask);
                 mask &= mask - 1;
                 const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b.a[u]), k));
                 // v[k] += ak * x: the index applies to the accumulator as source and as destination, not to
                 // the scalar coefficient nor to x (SRC1 is not indexed)
-                asm volatile("s_set_gpr_idx_on %3, gpr_idx(SRC2,DST)\n\t"
-                             "v_fma_f32 v0, %2, %4, v0\n\t"
-                             "s_set_gpr_idx_off"
-                             : "+{v[0:31]}"(lo), "+{v[32:63]}"(hi)
-                             : "s"(ak), "s"(k), "v"(b.x[u]));
+                if constexpr (NC == 1) {
+                    asm volatile("s_set_gpr_idx_on %3, gpr_idx(SRC2,DST)\n\t"
+                                 "v_fma_f32 v0, %2, %4, v0\n\t"
+                                 "s_set_gpr_idx_off"
+                                 : "+{v[0:31]}"(lo0), "+{v[32:63]}"(hi0)
+                                 : "s"(ak), "s"(k), "v"(b.x[u][0]));
+                } else {
+                    asm volatile("s_set_gpr_idx_on %5, gpr_idx(SRC2,DST)\n\t"
+                                 "v_fma_f32 v0, %4, %6, v0\n\t"
+                                 "v_fma_f32 v64, %4, %7, v64\n\t"
+                                 "s_set_gpr_idx_off"
+                                 : "+{v[0:31]}"(lo0), "+{v[32:63]}"(hi0), "+{v[64:95]}"(lo1), "+{v[96:127]}"(hi1)
+                                 : "s"(ak), "s"(k), "v"(b.x[u][0]), "v"(b.x[u][NC - 1]));
+                }
             }
         }
     };
-    Batch b0, b1;
+    // NB batches rotate: NB - 1 are in flight while one is walked (four instead of two, which the two-column
+    // form has the registers for, measured slower: 32.6 against 29.0 us -- the walk is bound by the instructions
+    // a wave issues, not by the latency of its loads).
+    constexpr int NB = 2;
+    Batch b[NB];
     constexpr int STEP = D1_WAVES * D1_UNROLL;
     int r = r0 + wave;
     if (r0 < r1) {
-        fetch(b0, r);
-        for (; r < r1; r += 2 * STEP) {
-            fetch(b1, r + STEP);
-            walk(b0);
-            fetch(b0, r + 2 * STEP);
-            walk(b1);
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) fetch(b[i], r + i * STEP);
+        for (; r < r1; r += NB * STEP) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                fetch(b[(i + NB - 1) % NB], r + (i + NB - 1) * STEP);
+                walk(b[i], r + i * STEP);
+            }
         }
     }
     // waves 4..7 -> 0..3, 2..3 -> 0..1, 1 -> 0
 #pragma unroll
     for (int half = D1_WAVES / 2; half >= 1; half >>= 1) {
         if (wave >= half && wave < 2 * half) {
+            float* o = &red[wave - half][0][lane * NC];
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
-                red[wave - half][k][lane] = lo[k];
-                red[wave - half][k + 32][lane] = hi[k];
+                o[k * 64 * NC] = lo0[k];
+                o[(k + 32) * 64 * NC] = hi0[k];
+                if constexpr (NC == 2) {
+                    o[k * 64 * NC + 1] = lo1[k];
+                    o[(k + 32) * 64 * NC + 1] = hi1[k];
+                }
             }
         }
         __syncthreads();
         if (wave < half) {
+            const float* o = &red[wave][0][lane * NC];
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
-                lo[k] += red[wave][k][lane];
-                hi[k] += red[wave][k + 32][lane];
+                lo0[k] += o[k * 64 * NC];
+                hi0[k] += o[(k + 32) * 64 * NC];
+                if constexpr (NC == 2) {
+                    lo1[k] += o[k * 64 * NC + 1];
+                    hi1[k] += o[(k + 32) * 64 * NC + 1];
+                }
             }
         }
         __syncthreads();
     }
     if (wave == 0) {
-        float* dst = partial + (long long)blockIdx.y * 64 * ldz + blockIdx.x * 64 + lane;
+        float* dst = partial + (long long)blockIdx.y * 64 * ldz + col;
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
-            dst[k * ldz] = lo[k];
-            dst[(k + 32) * ldz] = hi[k];
+            if constexpr (NC == 1) {
+                dst[k * ldz] = lo0[k];
+                dst[(k + 32) * ldz] = hi0[k];
+            } else {
+                xvec a, b;
+                a[0] = lo0[k]; a[NC - 1] = lo1[k];
+                b[0] = hi0[k]; b[NC - 1] = hi1[k];
+                *reinterpret_cast<xvec*>(dst + k * ldz) = a;
+                *reinterpret_cast<xvec*>(dst + (k + 32) * ldz) = b;
+            }
         }
     }
 }
@@ -631,8 +677,15 @@ int dw1_sparse(const float* adjc, int n, const float* dZ1c, int H, const int* ro
 {
     if (!dw1_sparse_applies(rows_max, n, H)) return set_error(GTG_ERR_INVALID, "dw1_sparse: shape not supported");
     ProfScope prof(s, "dw1_sparse", rows_max, H, n);
-    hipLaunchKernelGGL(dw1_sparse_kernel, dim3(H / 64, D1_CHUNKS), dim3(D1_THREADS), 0, s, adjc, n, dZ1c, H, rows_dev,
-                       (int)rows_max, partial);
+    // two columns per lane where that still leaves a block per CU (H / 128 slabs x 32 chunks)
+    const bool two = (H % 128) == 0 && H >= 1024 && (reinterpret_cast<uintptr_t>(dZ1c) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(partial) & 7) == 0;
+    if (two)
+        hipLaunchKernelGGL(dw1_sparse_kernel<2>, dim3(H / 128, D1_CHUNKS), dim3(D1_THREADS), 0, s, adjc, n, dZ1c, H,
+                           rows_dev, (int)rows_max, partial);
+    else
+        hipLaunchKernelGGL(dw1_sparse_kernel<1>, dim3(H / 64, D1_CHUNKS), dim3(D1_THREADS), 0, s, adjc, n, dZ1c, H,
+                           rows_dev, (int)rows_max, partial);
     if (int rc = check_launch("dw1_sparse_kernel")) return rc;
     // partial[chunk][i][c] -> dW1[c][i]
     hipLaunchKernelGGL(dw2_reduce_kernel, dim3((H + 31) / 32, 2), dim3(256), 0, s, partial, H, 64, dW1, n, n);
