@@ -563,8 +563,11 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     GemmDesc g;
     // dW2 = dT2c^T * H1c: from the pooled gradient and the winning rows where the shape allows (one aggregated
     // row of H1c per graph and pooled column), else as the dense product
+    const bool dw1_sp = dw1_sparse_applies(rows, n, H);
+    const bool dw2_deferred = dw1_sp && dw2_sparse_applies(B, n, d, H);  // dW2's partials are reduced beside dW1's
     if (dw2_sparse_applies(B, n, d, H)) {
-        GTG_TRY(dw2_sparse(adj, h1c, H, dpooled, argmax, meta, w.dT2c, planes ? w.proto_rows : nullptr, B, n, d, w.dw2, dW2, s));
+        GTG_TRY(dw2_sparse(adj, h1c, H, dpooled, argmax, meta, w.dT2c, planes ? w.proto_rows : nullptr, B, n, d, w.dw2, dW2,
+                           dw2_deferred, s));
     } else {
         g.A = w.dT2c; g.lda = d; g.a_kc = false;
         g.B = h1c; g.ldb = H; g.b_kc = false;
@@ -598,7 +601,8 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
         GTG_TRY(colsum_dev_and_short(w.dZ1c, rows, all_rows, H, H, w.cs, db1, dpooled, B, d, d, db2, s));
     // dW1[c][i] = sum over stored rows dZ1c[r][c] * adjc[r][i]   (prototype rows carry unit adjacency rows):
     // through the nonzeros of the adjacency rows where the shape allows, else as the dense product
-    if (dw1_sparse_applies(rows, n, H)) return dw1_sparse(adjc, n, w.dZ1c, H, all_rows, rows, w.dw1, dW1, s);
+    if (dw1_sp)
+        return dw1_sparse(adjc, n, w.dZ1c, H, all_rows, rows, w.dw1, dW1, dw2_deferred ? w.dw2 : nullptr, d, dW2, s);
     g = GemmDesc();
     g.A = w.dZ1c; g.lda = H; g.a_kc = false;
     g.B = adjc; g.ldb = n; g.b_kc = false;

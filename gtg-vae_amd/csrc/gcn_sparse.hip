@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void pool_sparse_kernel(const float* __restric
 // rows, g and am): the loads of graph t + 2 are issued before graph t is accumulated.  The columns won by a prototype row
 // arrive as n more items: row i of the prototype block of dT2c (the sum of g over the graphs whose maximum
 // row i won) times prototype row i of H1c.  Each group of graphs leaves a partial dW2, stored transposed (c along
-// the lanes: whole 256-byte runs); dw2_reduce_kernel adds the groups in order and transposes back: reproducible.
+// the lanes: whole 256-byte runs); dw_reduce_pair_kernel adds the groups in order and transposes back: reproducible.
 constexpr int DW_THREADS = 512;
 constexpr int DW_COLS = 64;
 constexpr int DW_LD = 65;
@@ -422,16 +422,31 @@ __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* 
     }
 }
 
-// dW2[c][h] = sum over groups of partial[group][h][c], groups in order; 32 x 32 tiles transposed through LDS so
-// that reads and writes are both whole 128-byte rows.
-// (h_valid <= H columns of each output row are stored, ld_out apart: the first layer's gradient keeps 64 rows
-// of partials whatever n is.)
-__global__ __launch_bounds__(256) void dw2_reduce_kernel(const float* __restrict__ partial, int d, int H,
-                                                         float* __restrict__ out, int ld_out, int h_valid)
+// out[c][h] = sum over groups of partial[group][h][c], groups in order; 32 x 32 tiles transposed through LDS so
+// that reads and writes are both whole 128-byte rows.  h_valid <= H columns of each output row are stored, ld_out
+// apart (the first layer's gradient keeps 64 rows of partials whatever n is).  Two jobs share a launch: the
+// first `blocks` blocks take job 0, the rest job 1 (a job with no blocks is skipped).
+struct DwReduceJob {
+    const float* partial;
+    int d, H;
+    float* out;
+    int ld_out, h_valid;
+    int bx, blocks;  // blocks along c; bx * ceil(H / 32) in all
+};
+
+__global__ __launch_bounds__(256) void dw_reduce_pair_kernel(const DwReduceJob j0, const DwReduceJob j1)
 {
     __shared__ float tile[32][33];
+    int b = blockIdx.x;
+    const bool first = b < j0.blocks;  // block-uniform
+    if (!first) b -= j0.blocks;
+    const float* __restrict__ partial = first ? j0.partial : j1.partial;
+    float* __restrict__ out = first ? j0.out : j1.out;
+    const int d = first ? j0.d : j1.d, H = first ? j0.H : j1.H;
+    const int ld_out = first ? j0.ld_out : j1.ld_out, h_valid = first ? j0.h_valid : j1.h_valid;
+    const int bx = first ? j0.bx : j1.bx;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
+    const int c0 = (b % bx) * 32, h0 = (b / bx) * 32;
     const long long plane = (long long)H * d;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -454,6 +469,21 @@ __global__ __launch_bounds__(256) void dw2_reduce_kernel(const float* __restrict
     }
 }
 
+inline DwReduceJob dw_reduce_job(const float* partial, int d, int H, float* out, int ld_out, int h_valid)
+{
+    DwReduceJob j;
+    j.partial = partial; j.d = d; j.H = H; j.out = out; j.ld_out = ld_out; j.h_valid = h_valid;
+    j.bx = (d + 31) / 32;
+    j.blocks = j.bx * ((H + 31) / 32);
+    return j;
+}
+
+int dw_reduce_pair(const DwReduceJob& j0, const DwReduceJob& j1, hipStream_t s)
+{
+    hipLaunchKernelGGL(dw_reduce_pair_kernel, dim3(j0.blocks + j1.blocks), dim3(256), 0, s, j0, j1);
+    return check_launch("dw_reduce_pair_kernel");
+}
+
 // ---------------------------------------------------------------------------
 // dW1 through the adjacency's sparsity.  With identity node features the first layer is Z1 = A W1^T + b1, so
 //   dW1[c][i] = sum over stored rows r of dZ1c[r][c] * adjc[r][i]
@@ -465,7 +495,7 @@ __global__ __launch_bounds__(256) void dw2_reduce_kernel(const float* __restrict
 // accumulator of column i -- 64 accumulators per lane, indexed by a scalar.  D1_UNROLL rows are in flight per
 // wave, the next batch requested before the current one is walked.  The eight waves' accumulators are added in
 // a fixed order through LDS and the block stores partial[chunk][i][c] (c along the lanes: 256-byte runs);
-// dw2_reduce_kernel adds the chunks in order and transposes: reproducible.
+// dw_reduce_pair_kernel adds the chunks in order and transposes: reproducible.
 // ---------------------------------------------------------------------------
 constexpr int D1_THREADS = 512;
 constexpr int D1_WAVES = D1_THREADS / 64;
@@ -651,7 +681,7 @@ size_t dw2_sparse_workspace(int d, int H) { return (size_t)DW_GROUPS * d * H * s
 
 int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, const int32_t* argmax, const int32_t* meta,
                const float* dT2c, const float* proto_rows, int64_t B, int n, int d, float* partial, float* dW2,
-               hipStream_t s)
+               bool defer_reduce, hipStream_t s)
 {
     if (!dw2_sparse_applies(B, n, d, H)) return set_error(GTG_ERR_INVALID, "dw2_sparse: shape not supported");
     if ((reinterpret_cast<uintptr_t>(partial) & 15) != 0 || (reinterpret_cast<uintptr_t>(dW2) & 15) != 0)
@@ -660,8 +690,10 @@ int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, co
     hipLaunchKernelGGL(dw2_sparse_kernel, dim3(H / DW_COLS, DW_GROUPS, (d + DW_CPB - 1) / DW_CPB), dim3(DW_THREADS), 0, s,
                        adj, h1c, H, dpool, argmax, meta, dT2c, proto_rows, (int)B, n, d, partial);
     if (int rc = check_launch("dw2_sparse_kernel")) return rc;
-    hipLaunchKernelGGL(dw2_reduce_kernel, dim3((d + 31) / 32, (H + 31) / 32), dim3(256), 0, s, partial, d, H, dW2, H, H);
-    return check_launch("dw2_reduce_kernel");
+    if (defer_reduce) return GTG_OK;
+    DwReduceJob none = dw_reduce_job(nullptr, 1, 32, nullptr, 1, 0);
+    none.blocks = 0;
+    return dw_reduce_pair(dw_reduce_job(partial, d, H, dW2, H, H), none, s);
 }
 
 bool dw1_sparse_applies(int64_t rows, int n, int H)
@@ -673,7 +705,7 @@ bool dw1_sparse_applies(int64_t rows, int n, int H)
 size_t dw1_sparse_workspace(int H) { return (size_t)D1_CHUNKS * 64 * H * sizeof(float); }
 
 int dw1_sparse(const float* adjc, int n, const float* dZ1c, int H, const int* rows_dev, int64_t rows_max, float* partial,
-               float* dW1, hipStream_t s)
+               float* dW1, const float* dw2_partial, int d, float* dW2, hipStream_t s)
 {
     if (!dw1_sparse_applies(rows_max, n, H)) return set_error(GTG_ERR_INVALID, "dw1_sparse: shape not supported");
     ProfScope prof(s, "dw1_sparse", rows_max, H, n);
@@ -687,9 +719,10 @@ int dw1_sparse(const float* adjc, int n, const float* dZ1c, int H, const int* ro
         hipLaunchKernelGGL(dw1_sparse_kernel<1>, dim3(H / 64, D1_CHUNKS), dim3(D1_THREADS), 0, s, adjc, n, dZ1c, H,
                            rows_dev, (int)rows_max, partial);
     if (int rc = check_launch("dw1_sparse_kernel")) return rc;
-    // partial[chunk][i][c] -> dW1[c][i]
-    hipLaunchKernelGGL(dw2_reduce_kernel, dim3((H + 31) / 32, 2), dim3(256), 0, s, partial, H, 64, dW1, n, n);
-    return check_launch("dw2_reduce_kernel");
+    // partial[chunk][i][c] -> dW1[c][i]; the deferred reduction of dW2's partials rides in the same launch
+    DwReduceJob j2 = dw_reduce_job(dw2_partial, d, H, dW2, H, H);
+    if (dw2_partial == nullptr) j2.blocks = 0;
+    return dw_reduce_pair(j2, dw_reduce_job(partial, H, 64, dW1, n, n), s);
 }
 
 }  // namespace gtg

@@ -250,19 +250,22 @@ int conv1_sparse(const float* adjc, int n, const float* W1, const float* b1, int
 // pooled (B, d) / argmax = max over the rows r < n_b of A_b T2c_b + b2, merged with the prototype rows' maximum;
 // meta as written by graph_meta; d a multiple of 4
 // dW2 = dT2c^T * H1c computed from the pooled gradient and the arg-max rows instead of the dense product
-// (gcn_sparse.hip); dT2c supplies only its prototype rows.  partial: dw2_sparse_workspace() bytes.
+// (gcn_sparse.hip); dT2c supplies only its prototype rows.  partial: dw2_sparse_workspace() bytes.  With
+// defer_reduce the partials are left for dw1_sparse to reduce (one launch fewer).
 bool dw2_sparse_applies(int64_t B, int n, int d, int H);
 size_t dw2_sparse_workspace(int d, int H);
 // proto_rows (nullable): the prototype rows' gradient as an (n, d) block of its own instead of rows R.. of dT2c
 int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, const int32_t* argmax, const int32_t* meta,
                const float* dT2c, const float* proto_rows, int64_t B, int n, int d, float* partial, float* dW2,
-               hipStream_t s);
+               bool defer_reduce, hipStream_t s);
 // dW1[c][i] = sum over the stored rows (count read on the device) of dZ1c[r][c] * adjc[r][i], walking the nonzeros
 // of each adjacency row (gcn_sparse.hip).  partial: dw1_sparse_workspace() bytes.
 bool dw1_sparse_applies(int64_t rows, int n, int H);
 size_t dw1_sparse_workspace(int H);
+// dw2_partial (nullable): partials of a dw2_sparse call made with defer_reduce, reduced into dW2 (d x H) by the
+// launch that reduces dW1's.
 int dw1_sparse(const float* adjc, int n, const float* dZ1c, int H, const int* rows_dev, int64_t rows_max, float* partial,
-               float* dW1, hipStream_t s);
+               float* dW1, const float* dw2_partial, int d, float* dW2, hipStream_t s);
 int pool_sparse(const float* adj, const float* t2c, const int32_t* meta, const float* b2, int64_t B, int n, int d,
                 float* pooled, int32_t* argmax, hipStream_t s);
 
