@@ -151,7 +151,7 @@ def test_compact_encoder_edge_cases(N, d):
     assert _relerr(outs[0][0], outs[1][0]) < 1e-6
 
 
-@pytest.mark.parametrize("B,N,d", [(130, 64, 512), (300, 10, 256), (256, 33, 288)])
+@pytest.mark.parametrize("B,N,d", [(130, 64, 512), (300, 10, 256), (256, 33, 288), (600, 10, 512)])
 def test_conv2_weight_gradient_through_the_pool_routing(B, N, d):
     """At B*d >= 65536 the compact backward takes dW2 from the pooled gradient and the winning rows
     (one aggregated row of H1 per graph and column) instead of the dense product: awkward graphs
@@ -159,7 +159,8 @@ def test_conv2_weight_gradient_through_the_pool_routing(B, N, d):
     complete, random), a batch that is not a multiple of the 16 graph groups, a width whose last
     wave of pooled columns is partly idle (288); all four gradients against the oracle.  At these
     sizes (2048 stored rows or more, hidden width a multiple of 64) conv1's weight gradient is
-    taken through the nonzeros of the adjacency rows as well: n = 64, 10 and 33 columns."""
+    taken through the nonzeros of the adjacency rows as well: n = 64, 10 and 33 columns, one column
+    per lane (2d = 512, 576) and two (2d = 1024, with n = 64 and with n = 10)."""
     from gtg_vae_amd import functional as Fn
     from oracle import graphvae_oracle as O
 
