@@ -156,8 +156,8 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_sparse_kernel(const float* _
 // merged with the maximum over the prototype rows n_b .. n-1 of T2c (a real row wins ties).
 // A block takes one graph and 128 columns: the graph's rows of T2c (at most 64 x 128 floats) are staged in
 // LDS with every load in flight at once, each wave walks every fourth adjacency row sparsely (lane k loads
-// A_b[r, k], ballot, one 8-byte LDS read per nonzero and lane), keeping a running maximum for its two columns;
-// the four waves' maxima are combined in row order.
+// A_b[r, k], ballot, one 8-byte LDS read per nonzero and lane) and takes every fourth prototype row as it is,
+// keeping a running maximum for its two columns; the four waves' maxima are combined in row order.
 constexpr int PS_COLS = 128;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -174,49 +174,69 @@ __global__ __launch_bounds__(256) void pool_sparse_kernel(const float* __restric
     const int b = blockIdx.y, c0 = blockIdx.x * PS_COLS;
     const int nb = meta[b], off = meta[B + b], R = meta[2 * B];
 
-    {   // stage rows off .. off + nb - 1, columns c0 .. c0 + 127 (d is a multiple of 4)
-        f32x4 v[8];
-        const int c4 = tid & 31, col = c0 + 4 * c4;
-        const int colc = min(col, d - 4), k_last = max(nb - 1, 0);
+    // Every global load of the block is issued here, back to back, so that the block pays one memory latency:
+    // the graph's rows of T2c for the LDS stage, this wave's adjacency rows, this lane's two columns of the
+    // prototype rows n_b .. n-1 (stored once after the R real rows) and of the bias.  All of them are
+    // unconditional loads at clamped indices: a load whose only use sits under a condition is moved under that
+    // branch by the compiler and waited for on the spot.
+    const int col = c0 + 2 * lane, colc = min(col, d - 2);  // (d is a multiple of 4: col < d implies col + 1 < d)
+    f32x2 bias;
+    bias[0] = b2[colc];
+    bias[1] = b2[colc + 1];
+    f32x4 v[8];
+    const int c4 = tid & 31, scol = min(c0 + 4 * c4, d - 4), k_last = max(nb - 1, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = (tid >> 5) + 8 * i;
-            v[i] = *reinterpret_cast<const f32x4*>(t2c + (long long)(off + min(k, k_last)) * d + colc);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = (tid >> 5) + 8 * i;
-            if (k < nb && col < d) *reinterpret_cast<f32x4*>(&T[k * PS_COLS + 4 * c4]) = v[i];
-        }
+    for (int i = 0; i < 8; ++i) {
+        const int k = (tid >> 5) + 8 * i;
+        v[i] = *reinterpret_cast<const f32x4*>(t2c + (long long)(off + min(k, k_last)) * d + scol);
     }
-    // this wave's adjacency rows, all in flight
     float a[16];
     const float* A = adj + (long long)b * n * n;
     const int lane_c = min(lane, n - 1);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int r = wave + 4 * t;
-        a[t] = keep_if(A[min(r, n - 1) * n + lane_c], r < nb && lane < nb);
+    for (int t = 0; t < 16; ++t) a[t] = A[min(wave + 4 * t, n - 1) * n + lane_c];
+    f32x2 pr[16];
+    const float* Q = t2c + (long long)R * d + colc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) pr[t] = *reinterpret_cast<const f32x2*>(Q + (long long)min(max(wave + 4 * t, nb), n - 1) * d);
+    // (pins the adjacency and bias loads above the LDS stage: left alone, the compiler sinks the ones whose first
+    // use is late in the walk below the barrier, where each is a memory latency of its own)
+    asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]),
+                 "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]),
+                 "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+#pragma unroll
+    for (int t = 0; t < 16; t += 4)
+        asm volatile("" : "+v"(pr[t]), "+v"(pr[t + 1]), "+v"(pr[t + 2]), "+v"(pr[t + 3]));
+    // rows past n_b and columns past d are staged too (repeats of valid memory) and never read back
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = (tid >> 5) + 8 * i;
+        *reinterpret_cast<f32x4*>(&T[k * PS_COLS + 4 * c4]) = v[i];
     }
-    const int col = c0 + 2 * lane;
-    f32x2 bias = {0.f, 0.f};
-    if (col < d) bias[0] = b2[col];
-    if (col + 1 < d) bias[1] = b2[col + 1];
+    const unsigned long long lanes_nb = nb >= 64 ? ~0ull : (1ull << nb) - 1;
     __syncthreads();
 
+    // Rows wave, wave + 4, ...: real rows r < n_b are walked sparsely, prototype rows n_b <= r < n are
+    // T2c's stored prototype rows plus the bias.  Strictly-greater updates in ascending row order keep the lowest
+    // row on ties, and a real row (lower index) therefore wins a tie against a prototype row.
     f32x2 best = {0.f, 0.f};
     int bi0 = -1, bi1 = -1;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int r = wave + 4 * t;
-        if (r >= nb) break;  // wave-uniform
-        unsigned long long mask = __ballot(a[t] != 0.f);
-        f32x2 acc = bias;
-        while (mask) {
-            const int k = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[t]), k));
-            acc += ak * *reinterpret_cast<const f32x2*>(&T[k * PS_COLS + 2 * lane]);
+        if (r >= n) break;  // wave-uniform
+        f32x2 acc;
+        if (r < nb) {
+            unsigned long long mask = __ballot(a[t] != 0.f) & lanes_nb;
+            acc = bias;
+            while (mask) {
+                const int k = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[t]), k));
+                acc += ak * *reinterpret_cast<const f32x2*>(&T[k * PS_COLS + 2 * lane]);
+            }
+        } else {
+            acc = pr[t] + bias;
         }
         if (bi0 < 0 || acc[0] > best[0]) {
             best[0] = acc[0];
@@ -239,29 +259,12 @@ __global__ __launch_bounds__(256) void pool_sparse_kernel(const float* __restric
     int bidx = -1;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const float v = wv[w][tid];
+        const float v2 = wv[w][tid];
         const int i = wi[w][tid];
-        if (i >= 0 && (bidx < 0 || v > bv || (v == bv && i < bidx))) {
-            bv = v;
+        if (i >= 0 && (bidx < 0 || v2 > bv || (v2 == bv && i < bidx))) {
+            bv = v2;
             bidx = i;
         }
-    }
-    // prototype rows n_b .. n-1, stored once after the R real rows
-    const float bc = b2[c];
-    float pv = 0.f;
-    int pi = -1;
-    const float* Q = t2c + (long long)R * d + c;
-#pragma unroll 4
-    for (int i = nb; i < n; ++i) {
-        const float v = Q[(long long)i * d] + bc;
-        if (pi < 0 || v > pv) {
-            pv = v;
-            pi = i;
-        }
-    }
-    if (pi >= 0 && (bidx < 0 || pv > bv)) {
-        bv = pv;
-        bidx = pi;
     }
     pooled[(long long)b * d + c] = bv;
     argmax[(long long)b * d + c] = bidx;
