@@ -678,13 +678,34 @@ __global__ __launch_bounds__(256) void pool_bwd_gather_planes_kernel(
     const int b = blockIdx.x - pg_blocks, tid = threadIdx.x;
     for (int i = b * 256 + tid; i < zero_count; i += B * 256) zero[i] = 0;   // the following GEMM's arrival counters
     const int nb = meta[b], off = meta[B + b];
+    // Every global load of the block is issued here, back to back and unconditionally (clamped indices; an entry
+    // read twice is stored twice with the same value): the graph's whole adjacency block, the winning rows and
+    // the pooled gradient.  As loops with data-dependent bounds and a gradient load that waited for the winning
+    // row they were four memory latencies one after the other.
     const float* src = adj + (int64_t)b * n * n;
-    for (int idx = tid; idx < nb * n; idx += 256) sadj[(idx / n) * 65 + (idx % n)] = src[idx];
-    for (int c = tid; c < d; c += 256) {
-        const int am = argmax[(int64_t)b * d + c];
-        const bool real = am < nb;    // a prototype row that won the maximum has no edge to a stored row
-        gS[c] = real ? dpool[(int64_t)b * d + c] : 0.f;
-        amS[c] = real ? am : 0;
+    const int nn_last = n * n - 1;
+    float av[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) av[q] = src[min(tid + 256 * q, nn_last)];
+    int amv[GP_MAX_D / 256];
+    float gv[GP_MAX_D / 256];
+#pragma unroll
+    for (int q = 0; q < GP_MAX_D / 256; ++q) {
+        const int c = min(tid + 256 * q, d - 1);
+        amv[q] = argmax[(int64_t)b * d + c];
+        gv[q] = dpool[(int64_t)b * d + c];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int idx = min(tid + 256 * q, nn_last);
+        sadj[(idx / n) * 65 + (idx % n)] = av[q];
+    }
+#pragma unroll
+    for (int q = 0; q < GP_MAX_D / 256; ++q) {
+        const int c = tid + 256 * q;         // entries from d on are written (a repeat of column d - 1) and never read
+        const bool real = amv[q] < nb;        // a prototype row that won the maximum has no edge to a stored row
+        gS[c] = real ? gv[q] : 0.f;
+        amS[c] = real ? amv[q] : 0;
     }
     __syncthreads();
     float scale = 1.f;
