@@ -26,6 +26,8 @@ _SIGS = {
     "gtg_launch_count": (c_int64, []),
     "gtg_profile_enable": (c_int, [c_int]),
     "gtg_profile_report": (c_int64, [ctypes.c_char_p, c_size_t]),
+    "gtg_stream_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    "gtg_stream_destroy": (c_int, [_P]),
     "gtg_mst_batched_triu": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "gtg_mst_batched_full": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "gtg_edge_prf": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P]),

@@ -174,6 +174,33 @@ int64_t gtg_profile_report(char* buf, size_t cap)
     return (int64_t)out.size();
 }
 
+// A stream whose handle nobody else holds (see include/gtgvae.h): for graph capture and for copies issued
+// from a loader thread.
+int gtg_stream_create(int device, void** stream)
+{
+    GTG_REQUIRE(stream != nullptr, "null pointer");
+    *stream = nullptr;
+    int count = 0, prev = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return set_error(GTG_ERR_INVALID, "gtg_stream_create: device %d of %d", device, count);
+    if (hipGetDevice(&prev) != hipSuccess) return set_error(GTG_ERR_LAUNCH, "gtg_stream_create: hipGetDevice failed");
+    hipError_t e = hipSetDevice(device);
+    hipStream_t s = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return set_error(GTG_ERR_LAUNCH, "gtg_stream_create: %s", hipGetErrorString(e));
+    *stream = (void*)s;
+    return GTG_OK;
+}
+
+int gtg_stream_destroy(void* stream)
+{
+    if (stream == nullptr) return GTG_OK;
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) return set_error(GTG_ERR_LAUNCH, "gtg_stream_destroy: %s", hipGetErrorString(e));
+    return GTG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // MST read-out and edge statistics
 // ---------------------------------------------------------------------------

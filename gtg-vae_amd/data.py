@@ -250,7 +250,12 @@ class DevicePrefetcher:
     ``depth`` batches ahead: a worker thread collates (the loader's own work),
     pins and starts the host-to-device copies on a side stream while the step
     of the previous batch runs; the consumer's stream only waits for the copy
-    event of the batch it is handed.  The batches are the loader's, in order."""
+    event of the batch it is handed.  The batches are the loader's, in order.
+
+    The side stream is the package's own copy stream of the device (streams.owned_stream: one per device,
+    created with hipStreamCreateWithFlags, so it can never be the pooled stream a HIP-graph capture or a
+    collective runs on), and the worker issues its device work under ``streams.device_work_lock``, which a
+    trainer holds while it captures its step: the worker waits out a capture instead of running into it."""
 
     def __init__(self, loader, device, depth: int = 2):
         dev = torch.device(device)
@@ -266,8 +271,10 @@ class DevicePrefetcher:
         import queue
         import threading
 
+        from .streams import device_work_lock, owned_stream
+
         q: "queue.Queue" = queue.Queue(self.depth)
-        copy_stream = torch.cuda.Stream(device=self.device)
+        copy_stream = owned_stream(self.device, "copy")
         stop = threading.Event()
 
         def put(item):
@@ -282,12 +289,13 @@ class DevicePrefetcher:
         def worker():
             try:
                 torch.cuda.set_device(self.device)
-                for host in self.loader:
-                    pinned = host.pin_memory()
-                    with torch.cuda.stream(copy_stream):
-                        dev = pinned.to(self.device)
-                        done = torch.cuda.Event()
-                        done.record(copy_stream)
+                for host in self.loader:          # collate: host work, outside the lock
+                    with device_work_lock:
+                        pinned = host.pin_memory()
+                        with torch.cuda.stream(copy_stream):
+                            dev = pinned.to(self.device)
+                            done = torch.cuda.Event()
+                            done.record(copy_stream)
                     if not put((dev, done, pinned)):   # the pinned source stays alive until the copy is consumed
                         return
                 put(None)

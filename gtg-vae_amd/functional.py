@@ -463,6 +463,9 @@ class LSTMFn(torch.autograd.Function):
               "gtg_lstm_fwd")
         ctx.save_for_backward(x, w_ih, w_hh, h0, c0, hs, cs, gates)
         ctx.dims = (T, B, I, H, bool(reverse))
+        # an output nobody differentiates through (the encoder uses h_n alone) reaches backward as None, which
+        # gtg_lstm_bwd takes as "no gradient", instead of a (T, B, H) block of zeros read at every time step
+        ctx.set_materialize_grads(False)
         last = 0 if reverse else T - 1
         return hs, hs[last].clone(), cs[last].clone()
 

@@ -111,17 +111,26 @@ class JointTrainer:
                     self._expected[b] += 1
                     named[k].register_post_accumulate_grad_hook(self._make_hook(b))
         self._waiting = list(self._expected)
-        self._launched = [False] * len(order)
+        self._next_bucket = 0
         self._reduce_now = False
 
     # ------------------------------------------------------------------ hooks
     def _make_hook(self, b: int):
         def hook(_param):
             self._waiting[b] -= 1
-            if self._waiting[b] == 0 and self._reduce_now and not self._launched[b]:
-                self._launched[b] = True
-                self.buckets.reduce(b)
+            if self._reduce_now:
+                self._launch_ready_buckets()
         return hook
+
+    def _launch_ready_buckets(self, force: bool = False):
+        """Start the all-reduce of every bucket that is final, strictly in index order: collectives of one
+        process group pair up across ranks by the order they were issued in, so a bucket whose gradients
+        happen to finish early waits for the buckets below it (and a rank with an empty shard, which issues
+        0, 1, 2 after the fact, matches).  ``force``: backward is over, whatever has not fired will not."""
+        n = len(self._waiting)
+        while self._next_bucket < n and (force or self._waiting[self._next_bucket] <= 0):
+            self.buckets.reduce(self._next_bucket)
+            self._next_bucket += 1
 
     # ------------------------------------------------------------------ params
     def named_params(self) -> Dict[str, torch.Tensor]:
@@ -167,7 +176,7 @@ class JointTrainer:
         B = batch.num_graphs
         self.flat_g.zero_()
         self._waiting = list(self._expected)
-        self._launched = [False] * len(self._expected)
+        self._next_bucket = 0
         self._reduce_now = update and self.world > 1
         if global_graphs is None:
             global_graphs = batch.global_graphs
@@ -180,9 +189,7 @@ class JointTrainer:
             res = {k: zero for k in ("loss", "text_acc", "kl", "graph_recon", "text_recon")}
         if update:
             if self.world > 1:
-                for b, done in enumerate(self._launched):   # empty shard, or a bucket whose hooks did not all fire
-                    if not done:
-                        self.buckets.reduce(b)
+                self._launch_ready_buckets(force=True)   # empty shard, or a bucket whose hooks did not all fire
                 self.buckets.finish()
             check(self.L.gtg_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                        self.numel, ptr(self.adam_state), self.lr, self.betas[0], self.betas[1],

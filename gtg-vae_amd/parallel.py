@@ -27,7 +27,18 @@ def local_device_index(local_rank: int) -> int:
     return local_rank % n if n > 0 else 0
 
 
-def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
+# A rank that stops answering must end the job, not hang it: every collective (and the rendezvous) gives up
+# after this many seconds, RCCL's watchdog then aborts the process with a non-zero exit code and the launcher
+# (torch.distributed.run, no restarts) takes the other ranks down.  PyTorch's default is ten minutes.
+DIST_TIMEOUT_S = 300.0
+
+
+def init_process_group(backend: Optional[str] = None, timeout_s: Optional[float] = None) -> Tuple[int, int, int]:
+    """Join the job the torchrun environment describes (a no-op for a single process).  With RCCL the
+    communicator is created here, eagerly (``device_id``), so that its set-up -- allocations, stream and event
+    creation -- is over before any step is captured into a HIP graph."""
+    import datetime
+
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -35,12 +46,18 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend is None:
             # GTG_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL wants one GPU per rank)
             backend = os.environ.get("GTG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("GTG_DIST_TIMEOUT_S") or DIST_TIMEOUT_S)
+        timeout = datetime.timedelta(seconds=timeout_s)
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            if torch.cuda.device_count() < 1:
+                raise RuntimeError("the nccl (RCCL) backend needs a GPU per rank; none is visible")
+            index = local_device_index(local_rank)
+            torch.cuda.set_device(index)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout,
+                                    device_id=torch.device("cuda", index))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local_rank, world
 
 

@@ -23,9 +23,6 @@ from . import functional as Fn
 from .noise import noisy
 
 
-_SIDE_STREAMS = {}   # device index -> torch.cuda.Stream (DAE._side_stream)
-
-
 class TextModel(nn.Module):
     def __init__(self, vocabsize, initrange=0.1):
         super().__init__()
@@ -54,12 +51,12 @@ class DAE(TextModel):
 
     @staticmethod
     def _side_stream(device):
-        """A second stream on ``device`` (one per device, kept outside the module so that the module still copies
-        and pickles), for work that runs beside the current stream."""
-        key = torch.device(device).index
-        if key not in _SIDE_STREAMS:
-            _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-        return _SIDE_STREAMS[key]
+        """A second stream on ``device`` for work that runs beside the current stream: the package's own
+        ``lstm`` stream (one per device, created outside PyTorch's recycled stream pool and kept outside the
+        module so that the module still copies and pickles)."""
+        from .streams import owned_stream
+
+        return owned_stream(device, "lstm")
 
     def run_lstm(self, mod, emb, hidden=None, need_output=True):
         """``mod(emb, hidden)`` for a one-layer ``nn.LSTM``: through functional.lstm, one call per direction, when

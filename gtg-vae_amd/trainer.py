@@ -18,6 +18,11 @@ from . import _lib
 from ._lib import check, ptr
 from .data import GraphBatch
 from .parallel import GradBuckets, shard_weight
+from .streams import device_work_lock, owned_stream
+
+# Captured steps kept per trainer, one per (batch size, update, edge capacity): an epoch whose last batch is
+# short alternates between two shapes and must not re-capture either.  Oldest out beyond this many.
+_MAX_GRAPHS = 16
 
 # (state_dict key, shape as a function of (f, d, hid, m)); bucket 0 = decoder +
 # latent head (gradients final before the encoder's backward starts), bucket 1 = encoder.
@@ -93,11 +98,12 @@ class GraphVAETrainer:
         # shards of a batch are unequal; it is 1 otherwise.
         self.kl_w_dev = torch.ones(2, dtype=torch.float32, device=self.dev)
         self._kl_w, self._shard_w = 1.0, 1.0
+        self.scalars = torch.zeros(2, dtype=torch.float32, device=self.dev)  # [recon, kl]
         self._B = 0
         self._cap_B = 0
         self._cap_E = 0
-        self._graph = None
-        self._graph_key = None
+        self._graphs: Dict[tuple, list] = {}
+        self.captures = 0     # how many times a step has been captured (tests, diagnostics)
         if max_batch:
             self._ensure_capacity(max_batch, max_edges or max_batch * nmax * 4)
 
@@ -174,13 +180,16 @@ class GraphVAETrainer:
         self.dlogits = torch.empty((B, m), **f32)  # d(recon loss)/d(decoder logits), written by the loss kernel
         self.dz = torch.empty((B, d), **f32)
         self.dh = torch.empty((B, d), **f32)
-        self.scalars = torch.zeros(2, **f32)  # [recon, kl]
         nbytes = max(L.gtg_encoder_compact_fwd_workspace_bytes(B, n, d), L.gtg_encoder_compact_bwd_workspace_bytes(B, n, d),
                      L.gtg_latent_workspace_bytes(B, d), L.gtg_decoder_bwd_workspace_bytes(B, d, hid, m),
                      L.gtg_bce_workspace_bytes(B))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._cap_B, self._cap_E = B, E
-        self._graph = None
+        self.drop_graphs()       # they hold the old buffers' addresses
+
+    def drop_graphs(self):
+        """Forget every captured step (after anything a capture froze has changed: buffers, matrix mode)."""
+        self._graphs.clear()
 
     def load_batch(self, batch: GraphBatch, eps: torch.Tensor, global_graphs: Optional[int] = None):
         """Copy one batch into the step's static input buffers.  The edge list
@@ -354,41 +363,55 @@ class GraphVAETrainer:
                 self._seg_adam(torch.cuda.current_stream(self.dev).cuda_stream)
             return {"recon": self.scalars[0], "kl": self.scalars[1]}
         if use_graph:
-            key = (B, update, self.ei.shape[1])
-            if self._graph is None or self._graph_key != key:
-                self._capture(B, update)
-                self._graph_key = key
-            self._run_segments([None if g is None else g.replay for g in self._graph], update)
+            key = (B, update, self.ei.shape[1], self.matrix_mode)
+            graphs = self._graphs.get(key)
+            if graphs is None:
+                graphs = self._capture(B, update)
+                while len(self._graphs) >= _MAX_GRAPHS:
+                    self._graphs.pop(next(iter(self._graphs)))
+                self._graphs[key] = graphs
+            self._run_segments([None if g is None else g.replay for g in graphs], update)
         else:
             self._launch(B, update, torch.cuda.current_stream(self.dev).cuda_stream)
         return {"recon": self.scalars[0], "kl": self.scalars[1]}
 
     def _capture(self, B: int, update: bool):
+        """The step's segments as HIP graphs, captured on the package's own capture stream.
+
+        That stream is created once per device with hipStreamCreateWithFlags (streams.owned_stream), so its
+        handle is not one of PyTorch's 32 pooled streams: no ``torch.cuda.Stream()`` drawn elsewhere (a
+        loader's copy stream, the collectives' streams) can turn out to be the stream under capture.  The
+        whole capture, warm-up included, holds ``device_work_lock``, which the prefetching loader's thread
+        takes around every pin -> copy -> record: no thread of this package issues device work meanwhile."""
         segs = self._segments(B, update)
         cur = torch.cuda.current_stream(self.dev)
-        # warm up outside capture (no collectives: the optimiser state is rolled back below)
-        side = torch.cuda.Stream(device=self.dev)
-        side.wait_stream(cur)
-        snap = (self.flat_p.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
-        with torch.cuda.stream(side):
+        cap = owned_stream(self.dev, "capture")
+        if cap.cuda_stream == cur.cuda_stream:
+            raise _lib.GtgError("the step cannot be captured from inside its own capture stream")
+        with device_work_lock:
+            # warm up outside capture (no collectives: the optimiser state is rolled back below)
+            snap = (self.flat_p.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.adam_state.clone())
+            cap.wait_stream(cur)
+            with torch.cuda.stream(cap):
+                for f in segs:
+                    if f is not None:
+                        f(cap.cuda_stream)
+            graphs = []
             for f in segs:
-                if f is not None:
-                    f(side.cuda_stream)
-        cur.wait_stream(side)
-        graphs = []
-        for f in segs:
-            if f is None:
-                graphs.append(None)
-                continue
-            g = torch.cuda.CUDAGraph()
-            # thread_local: a loader thread that pins or copies on this device meanwhile (data.DevicePrefetcher)
-            # must not invalidate the capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                f(torch.cuda.current_stream(self.dev).cuda_stream)
-            graphs.append(g)
-        self.flat_p.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
-        self.adam_state.copy_(snap[3])
-        self._graph = graphs
+                if f is None:
+                    graphs.append(None)
+                    continue
+                g = torch.cuda.CUDAGraph()
+                # thread_local: threads this package does not own (the collectives' watchdog, a caller's own
+                # loader) may call the runtime meanwhile without invalidating the capture
+                with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                    f(cap.cuda_stream)
+                graphs.append(g)
+            cur.wait_stream(cap)
+            self.flat_p.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
+            self.adam_state.copy_(snap[3])
+        self.captures += 1
+        return graphs
 
     def step(self, batch: GraphBatch, eps: torch.Tensor, kl_w: float = 1.0, update: bool = True,
              use_graph: bool = False):

@@ -86,6 +86,17 @@ int64_t gtg_launch_count(void);
 int gtg_profile_enable(int on);
 int64_t gtg_profile_report(char* buf, size_t cap);
 
+/* Streams of the caller's own.  No counterpart in the reference (which issues everything on PyTorch's
+ * current stream, src/train.py:302-314); they exist for hosts whose stream objects come from a shared,
+ * recycled pool (PyTorch hands out 32 pooled streams per device round-robin, its collectives' streams
+ * included), where "a new stream" can be a handle some other thread is already issuing work on -- fatal
+ * for a stream that is about to capture a HIP graph.  gtg_stream_create makes a non-blocking stream on
+ * `device` with hipStreamCreateWithFlags, so its handle is shared with nobody; the current device of the
+ * calling thread is left as it was.  gtg_stream_destroy releases it (the caller must have drained it).
+ * These two are the only entry points that create or destroy a runtime object. */
+int gtg_stream_create(int device, void** stream);
+int gtg_stream_destroy(void* stream);
+
 /* ---- maximum-spanning-tree read-out ------------------------------------
  * Replaces mst_graph / helper_mst / maximumSpanningTree / findMaxVertex /
  * printMaximumSpanningTree (src/maxspantree.py:118-163, 61-115, 7-31, 35-58),

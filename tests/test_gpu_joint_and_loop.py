@@ -125,32 +125,6 @@ def test_named_config_training_step_matches_oracle(name, B, N, d, hid, mode):
             assert _relerr(tr.named_grads()[k], want[k].grad) < 1e-4, (name, mode, use_graph, k)
 
 
-def test_train_and_dev_loop_runs_and_learns(capsys):
-    """train.py:284-355 / 228-282 mirrored: per-epoch KL weight min(epoch/500, 1), batch-size-weighted epoch
-    means, dev pass with the batched spanning-tree read-out; the printed field names are the reference's."""
-    from gtg_vae_amd.data import DataLoader, synth_graph_list
-    from gtg_vae_amd.train import dev, train
-    from gtg_vae_amd.trainer import GraphVAETrainer
-
-    N, d, hid = 10, 32, 64
-    data = synth_graph_list(300, N, seed=1)
-    trn, dv = DataLoader(data[:256], batch_size=64, nmax=N), DataLoader(data[256:], batch_size=64, nmax=N)
-    tr = GraphVAETrainer(N, d, hid, N, device="cuda", seed=0, lr=1e-2)
-    gen = torch.Generator().manual_seed(0)
-    hist = train(trn, dv, tr, epochs=6, generator=gen)
-    printed = capsys.readouterr().out
-    for field in ("Epoch loss:", "Epoch graph_recon loss:", "Epoch joint_kl_loss:", "kl_anneal_w:", "DEV",
-                  "Epoch edge_recall:", "Epoch edge_precision:"):
-        assert field in printed
-    assert hist[0]["kl"] >= 0 and all(np.isfinite(h["loss"]) for h in hist)
-    assert hist[-1]["graph_recon"] < 0.8 * hist[0]["graph_recon"]       # it learns
-    last = hist[-1]["dev"]
-    assert 0.0 <= last["edge_recall"] <= 1.0 and 0.0 <= last["edge_precision"] <= 1.0
-    # ragged tail: 300 - 256 = 44 dev graphs in one short batch
-    again = dev(dv, tr, 0, 0.0, gen, quiet=True)
-    assert np.isfinite(again["loss"])
-
-
 @pytest.mark.parametrize("case", range(14))
 def test_random_awkward_shapes_match_oracle(case):
     """Odd sizes end to end (N from 1 to 64, single-graph batches, d or hid of 1, non-multiples of every
@@ -210,135 +184,3 @@ def test_bf16_matrix_mode_meets_the_bf16_tolerances():
         assert cos.item() >= 0.999, (k, cos.item())
         exact = exact and _relerr(tr.named_grads()[k], p[k].grad) < 1e-6
     assert not exact        # the coarse pipe really ran
-
-
-def test_device_prefetcher_yields_the_loaders_batches_in_order():
-    """The prefetching loader (worker thread, pinned memory, side-stream copies) hands over exactly the
-    loader's batches, ragged tail included, and a training epoch through it equals the inline epoch."""
-    from gtg_vae_amd.data import DataLoader, DevicePrefetcher, synth_graph_list
-    from gtg_vae_amd.train import train
-    from gtg_vae_amd.trainer import GraphVAETrainer
-
-    N = 12
-    data = synth_graph_list(150, N, seed=3)
-    loader = DataLoader(data, batch_size=32, nmax=N)
-    got = list(DevicePrefetcher(loader, "cuda", depth=3))
-    want = list(loader)
-    assert len(got) == len(want) == 5 and got[-1].num_graphs == 150 - 4 * 32
-    for g, w in zip(got, want):
-        assert g.edge_index.is_cuda and torch.equal(g.edge_index.cpu(), w.edge_index)
-        assert torch.equal(g.adj_padded.cpu(), w.adj_padded) and torch.equal(g.gold_bits.cpu(), w.gold_bits)
-        assert g.gold_edges == w.gold_edges and g.num_graphs == w.num_graphs
-    runs = []
-    # the third arm captures the step's HIP graphs while the prefetcher's worker thread pins and copies batches
-    for wrap, use_graph in ((False, False), (True, False), (True, True)):
-        tr = GraphVAETrainer(N, 16, 32, N, device="cuda", seed=1)
-        ld = DevicePrefetcher(loader, "cuda") if wrap else loader
-        hist = train(ld, None, tr, epochs=2, generator=torch.Generator().manual_seed(0), quiet=True,
-                     use_graph=use_graph)
-        runs.append((tr.flat_p.clone(), hist[-1]["loss"]))
-    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
-    assert torch.equal(runs[0][0], runs[2][0]) and runs[0][1] == runs[2][1]
-
-    # an exception in the worker surfaces in the consumer
-    class Boom:
-        dataset = []
-
-        def __len__(self):
-            return 1
-
-        def __iter__(self):
-            yield want[0]
-            raise RuntimeError("loader failed")
-
-    it = iter(DevicePrefetcher(Boom(), "cuda"))
-    next(it)
-    with pytest.raises(RuntimeError, match="loader failed"):
-        next(it)
-
-
-def test_device_dataset_gather_equals_host_collate():
-    """Batches gathered on the device from the HBM-resident dataset equal the host collate (edge list up to the
-    padding, targets) for sequential and permuted ids, ragged tail included; bad ids and overflow are flagged;
-    training through load_indices equals training through load_batch bit for bit."""
-    from gtg_vae_amd.data import DataLoader, DeviceDataset, collate, synth_graph_list
-    from gtg_vae_amd.trainer import GraphVAETrainer
-
-    N, B = 12, 32
-    data = synth_graph_list(150, N, seed=3)
-    ds = DeviceDataset(data, N, "cuda")
-    tr = GraphVAETrainer(N, 16, 32, N, device="cuda", seed=1)
-    gen = torch.Generator().manual_seed(0)
-    for shuffle in (False, True):
-        for ids in ds.batches(B, shuffle=shuffle, generator=gen):
-            host = collate([data[i] for i in ids.tolist()], N)
-            eps = torch.zeros(len(ids), 16, device="cuda")
-            tr.load_indices(ds, ids, eps)
-            torch.cuda.synchronize()
-            assert tr.edges_ok()
-            E = host.edge_index.shape[1]
-            assert torch.equal(tr.ei[:, :E].cpu(), host.edge_index)
-            assert bool((tr.ei[:, E:] == 0).all())
-            assert torch.equal(tr.target[: len(ids)].cpu(), host.adj_padded)
-    # flags
-    tr.load_indices(ds, torch.tensor([0, 151, 2], device="cuda"), torch.zeros(3, 16, device="cuda"))
-    assert not tr.edges_ok()
-    tr.load_indices(ds, torch.tensor([0, 1, 2], device="cuda"), torch.zeros(3, 16, device="cuda"))
-    assert tr.edges_ok()
-    # same training trajectory as the host path
-    runs = []
-    for mode in ("host", "device"):
-        t2 = GraphVAETrainer(N, 16, 32, N, device="cuda", seed=1, max_batch=B, max_edges=B * ds.max_edges_per_graph)
-        g2 = torch.Generator().manual_seed(7)
-        for epoch in range(2):
-            for i, ids in enumerate(ds.batches(B)):
-                eps = torch.randn(len(ids), 16, generator=g2).cuda()
-                if mode == "host":
-                    t2.load_batch(collate([data[j] for j in ids.tolist()], N).to("cuda"), eps)
-                else:
-                    t2.load_indices(ds, ids, eps)
-                t2.run_loaded(update=True, use_graph=(mode == "device"))
-        torch.cuda.synchronize()
-        runs.append(t2.flat_p.clone())
-    assert torch.equal(runs[0], runs[1])
-
-
-def test_train_loop_over_the_device_resident_dataset():
-    """train() fed by DeviceLoader (ids of an HBM-resident dataset) follows the host-loader trajectory exactly."""
-    from gtg_vae_amd.data import DataLoader, DeviceDataset, DeviceLoader, synth_graph_list
-    from gtg_vae_amd.train import train
-    from gtg_vae_amd.trainer import GraphVAETrainer
-
-    N = 10
-    data = synth_graph_list(200, N, seed=5)
-    runs = []
-    for kind in ("host", "device"):
-        tr = GraphVAETrainer(N, 16, 32, N, device="cuda", seed=2)
-        ld = DataLoader(data, 64, N) if kind == "host" else DeviceLoader(DeviceDataset(data, N, "cuda"), 64)
-        hist = train(ld, None, tr, epochs=3, generator=torch.Generator().manual_seed(1), quiet=True,
-                     use_graph=(kind == "device"))
-        assert tr.edges_ok()
-        runs.append((tr.flat_p.clone(), [h["loss"] for h in hist]))
-    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
-
-
-def test_data_parallel_step_on_gpu_equals_full_batch_oracle():
-    """Two ranks (gloo, both on this GPU) each train on half of every batch through the HIP kernels, eager and
-    graph replay, with the bucketed gradient all-reduce between the step's pieces: the parameters must follow
-    the oracle's full-batch Adam steps and stay identical on both ranks (tests/dp_gpu_worker.py)."""
-    import json
-    import socket
-    import subprocess
-
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, GTG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(here, "dp_gpu_worker.py")], env=env, capture_output=True, text=True, timeout=170)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["ranks_identical"] and out["worst_abs_param_error"] < 2e-5

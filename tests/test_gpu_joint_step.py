@@ -143,51 +143,3 @@ def test_joint_trainer_adam_steps_follow_oracle():
         assert got[k].data_ptr() != tr.named_params()[k].data_ptr()            # state_dict hands out copies
     mod = dict(tr.model.named_parameters())
     assert all(mod[k].data_ptr() == tr.named_params()[k].data_ptr() for k in mod)   # one copy of every weight
-
-
-def test_joint_train_and_dev_loop_runs(capsys):
-    """train.py:284-355 / 228-282 for the joint model: the reference's printed fields, dropout and word
-    noise on in training, spanning-tree statistics in the dev pass, and it learns the sentences."""
-    import numpy as np
-
-    from gtg_vae_amd.data import DataLoader, synth_graph_list
-    from gtg_vae_amd.joint_trainer import JointTrainer
-    from gtg_vae_amd.train import train_joint
-
-    N, d, hid, vocab = 10, 32, 64, 40
-    data = synth_graph_list(160, N, seed=1, vocab=vocab, max_len=10)
-    trn, dv = DataLoader(data[:128], batch_size=32, nmax=N), DataLoader(data[128:], batch_size=32, nmax=N)
-    tr = JointTrainer(N, d, hid, N, vocab, 0, device="cuda", seed=0, lr=3e-3, train_graph_recon=True)
-    torch.manual_seed(0)
-    hist = train_joint(trn, dv, tr, epochs=5, generator=torch.Generator().manual_seed(0))
-    printed = capsys.readouterr().out
-    for field in ("Epoch loss:", "Epoch graph_recon loss:", "Epoch text_recon_loss:", "Epoch joint_kl_loss:",
-                  "Epoch text_acc:", "kl_anneal_w:", "DEV", "Epoch edge_recall:", "Epoch edge_precision:"):
-        assert field in printed
-    assert all(np.isfinite(h["loss"]) for h in hist)
-    assert hist[-1]["text_recon"] < hist[0]["text_recon"] and hist[-1]["graph_recon"] < hist[0]["graph_recon"]
-    last = hist[-1]["dev"]
-    assert 0.0 <= last["edge_recall"] <= 1.0 and 0.0 <= last["text_acc"] <= 1.0
-
-
-def test_joint_data_parallel_step_on_gpu_equals_full_batch_oracle():
-    """Two ranks (gloo, both on this GPU) train the joint model on their shards of every batch, unequal and
-    empty shards included; parameters must follow the oracle's full-batch Adam steps and stay identical on
-    both ranks (tests/dp_joint_gpu_worker.py)."""
-    import json
-    import socket
-    import subprocess
-
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, GTG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(here, "dp_joint_gpu_worker.py")], env=env, capture_output=True, text=True,
-                         timeout=170)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["ranks_identical"] and out["worst_abs_param_error"] < 1e-6 and out["worst_rel_grad_error"] < 1e-4
