@@ -63,6 +63,13 @@ _SIGS = {
     "gtg_lstm_bwd": (c_int, [_P] * 11 + [c_int] * 5 + [_P] * 6 + [c_int, _P, c_size_t, _P]),
     "gtg_proj_ce_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "gtg_proj_ce_bwd": (c_int, [_P] * 5 + [c_int64, c_int64, c_int, c_int] + [_P] * 3 + [c_int, _P, c_size_t, _P]),
+    "gtg_word_drop": (c_int, [_P, c_int, c_int, c_int64, c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P, _P]),
+    "gtg_embed_dropout_fwd": (c_int, [_P, _P, c_int64, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint64, _P, c_int,
+                                      _P, _P, _P]),
+    "gtg_embed_dropout_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "gtg_embed_dropout_bwd": (c_int, [_P, _P, c_int64, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P,
+                                      c_int, _P, c_size_t, _P]),
+    "gtg_dropout": (c_int, [_P, c_int64, c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     "gtg_adam_step": (c_int, [_P] * 4 + [c_int64, _P, c_float, c_float, c_float, c_float, c_float, _P]),
     "gtg_gemm_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, c_int, _P, c_int, _P, c_size_t, c_int, _P]),
     "gtg_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

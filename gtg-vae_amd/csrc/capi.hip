@@ -957,6 +957,68 @@ int gtg_lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const flo
 }
 
 // ---------------------------------------------------------------------------
+// text branch: word drop, embedding lookup + dropout, dropout
+// ---------------------------------------------------------------------------
+int gtg_word_drop(const int64_t* tokens, int T, int B, int64_t padidx, float p, uint64_t seed, uint64_t stream_id,
+                  const uint8_t* keep, int64_t* out, void* stream)
+{
+    GTG_REQUIRE(T >= 1 && B >= 1 && p >= 0.f && p <= 1.f, "bad size or probability");
+    GTG_REQUIRE(tokens && out && tokens != out, "null pointer, or input and output alias");
+    return word_drop(tokens, T, B, padidx, p, seed, stream_id, keep, out, (hipStream_t)stream);
+}
+
+int gtg_embed_dropout_fwd(const float* table, const int64_t* ids, int64_t rows, int64_t vocab, int dim, float p,
+                          uint64_t seed, uint64_t stream_id, const float* add, int add_rows, float* out, int32_t* err,
+                          void* stream)
+{
+    GTG_REQUIRE(rows >= 1 && rows < (1ll << 31) && vocab >= 1 && dim >= 4 && dim % 4 == 0 && p >= 0.f && p < 1.f,
+                "bad size or probability (dim must be a multiple of 4)");
+    GTG_REQUIRE(table && ids && out && (add == nullptr || add_rows >= 1), "null pointer");
+    GTG_REQUIRE(aligned16(table) && aligned16(out) && aligned16(add), "table, add and out must be 16-byte aligned");
+    return embed_dropout_fwd(table, ids, rows, vocab, dim, p, seed, stream_id, add, add_rows, out, err, (hipStream_t)stream);
+}
+
+size_t gtg_embed_dropout_bwd_workspace_bytes(int64_t rows, int dim, int add_rows)
+{
+    Carver c(nullptr, 0);
+    c.take<char>(embed_dropout_bwd_workspace(rows, dim));
+    if (add_rows > 0) c.take<char>(colsum_workspace(rows / add_rows, add_rows * dim));
+    return c.off;
+}
+
+int gtg_embed_dropout_bwd(const float* dout, const int64_t* ids, int64_t rows, int64_t vocab, int dim, float p,
+                          uint64_t seed, uint64_t stream_id, float* dtable, float* d_add, int add_rows, void* ws,
+                          size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(rows >= 1 && vocab >= 1 && dim >= 4 && dim % 4 == 0 && p >= 0.f && p < 1.f,
+                "bad size or probability (dim must be a multiple of 4)");
+    GTG_REQUIRE(dout && ids && (dtable || d_add), "null pointer");
+    GTG_REQUIRE(d_add == nullptr || (add_rows >= 1 && rows % add_rows == 0 && (int64_t)add_rows * dim < (1ll << 31)),
+                "rows must be a multiple of add_rows");
+    GTG_REQUIRE(aligned16(dout) && aligned16(dtable) && aligned16(d_add) && aligned16(ws),
+                "dout, dtable, d_add and ws must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    Carver c(ws, ws_bytes);
+    char* scatter_ws = c.take<char>(embed_dropout_bwd_workspace(rows, dim));
+    float* cs = d_add ? reinterpret_cast<float*>(c.take<char>(colsum_workspace(rows / add_rows, add_rows * dim))) : nullptr;
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_embed_dropout_bwd: workspace too small");
+    if (dtable)
+        GTG_TRY(embed_dropout_bwd(dout, ids, rows, vocab, dim, p, seed, stream_id, dtable, scatter_ws,
+                                  embed_dropout_bwd_workspace(rows, dim), s));
+    if (d_add)  // the added rows are shared by the rows r, r + add_rows, ...: column sums of dout seen as (rows / add_rows, add_rows * dim)
+        GTG_TRY(colsum(dout, rows / add_rows, add_rows * dim, add_rows * dim, cs, d_add, s));
+    return GTG_OK;
+}
+
+int gtg_dropout(const float* x, int64_t count, float p, uint64_t seed, uint64_t stream_id, float* y, void* stream)
+{
+    GTG_REQUIRE(count >= 0 && count % 4 == 0 && p >= 0.f && p < 1.f, "count must be a multiple of 4, p in [0, 1)");
+    if (count == 0) return GTG_OK;
+    GTG_REQUIRE(x && y && aligned16(x) && aligned16(y), "null or misaligned pointer");
+    return dropout_map(x, count, p, seed, stream_id, y, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
 // optimiser
 // ---------------------------------------------------------------------------
 int gtg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, void* state16,

@@ -499,3 +499,132 @@ def lstm(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, reverse=False, matrix_mode
 def proj_ce(H, W, b, targets, padidx, matrix_mode=None):
     """Per-token cross-entropy of the projected decoder outputs and the arg-max token; see ProjCEFn."""
     return ProjCEFn.apply(H, W, b, targets, padidx, matrix_mode)
+
+
+# ---------------------------------------------------------------------------
+# text branch: word drop, embedding lookup + dropout, dropout
+# ---------------------------------------------------------------------------
+def _rng_key():
+    """(seed, stream id) for one randomised forward call: the seed is PyTorch's (``torch.manual_seed``), the stream
+    id is drawn from PyTorch's default CPU generator -- no device work, no synchronisation, and a run repeats
+    under the same ``torch.manual_seed`` exactly as stock dropout does.  The library's keep decisions are a pure
+    function of (seed, stream id, element index), so the backward regenerates the forward's mask from this pair."""
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    sid = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return seed, sid
+
+
+@_on_tensor_device
+def word_drop(x: torch.Tensor, padidx: int, p: float, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """noise.word_drop (noise.py:12-22) on the device: x (T, B) int64 token ids; every token of a column but the
+    first is dropped with probability p, the kept ones move up in order, the tail is filled with padidx.
+    ``keep`` (T, B) bool / uint8: an explicit keep mask instead of the random one."""
+    _lib.require_cuda(x)
+    T, B = x.shape
+    x = x.contiguous().long()
+    out = torch.empty_like(x)
+    k = None if keep is None else keep.to(device=x.device, dtype=torch.uint8).contiguous()
+    seed, sid = (0, 0) if k is not None else _rng_key()
+    check(_lib.lib().gtg_word_drop(ptr(x), T, B, int(padidx), float(p), seed, sid, ptr(k), ptr(out), stream_ptr()),
+          "gtg_word_drop")
+    return out
+
+
+class EmbedDropoutFn(torch.autograd.Function):
+    """drop(weight[ids]) (+ add broadcast over the leading dimension): text_vae.py:56 and :62 in one kernel, the
+    backward an ordered scatter-add.  ids (T, B) int64, weight (V, D), add (B, D) or None -> (T, B, D).
+
+    A weight whose ``grad_inplace`` attribute is true and whose ``.grad`` is already a dense tensor (JointTrainer's
+    flat gradient buffer) receives its gradient by accumulation into that tensor -- the backward then returns None
+    for it, and no (V, D) temporary is made; otherwise a dense (V, D) gradient is returned to autograd."""
+
+    @staticmethod
+    @_on_tensor_device
+    def forward(ctx, ids, weight, add, p):
+        L = _lib.lib()
+        _lib.require_cuda(ids, weight, add)
+        T, B = ids.shape
+        V, D = weight.shape
+        if D % 4:
+            raise _lib.GtgError("embed_dropout: the embedding width must be a multiple of 4")
+        w = _f32c(weight)
+        a = _f32c(add)
+        if a is not None and tuple(a.shape) != (B, D):
+            raise _lib.GtgError("embed_dropout: add must be (B, D)")
+        ids_c = ids.contiguous().long()
+        out = torch.empty((T, B, D), dtype=torch.float32, device=w.device)
+        err = torch.zeros(1, dtype=torch.int32, device=w.device) if EmbedDropoutFn.check_ids else None
+        seed, sid = _rng_key() if p > 0 else (0, 0)
+        check(L.gtg_embed_dropout_fwd(ptr(w), ptr(ids_c), T * B, V, D, float(p), seed, sid, ptr(a), B if a is not None else 0,
+                                      ptr(out), ptr(err), stream_ptr()), "gtg_embed_dropout_fwd")
+        if err is not None and int(err.item()):
+            raise _lib.GtgError("embed_dropout: a token id lies outside the embedding table")
+        ctx.save_for_backward(ids_c)
+        ctx.weight = weight
+        ctx.key = (float(p), seed, sid, V, D, B, a is not None)
+        return out
+
+    check_ids = False   # reading the flag back is a host sync: for tests and debugging
+
+    @staticmethod
+    @_on_tensor_device
+    def backward(ctx, dout):
+        L = _lib.lib()
+        (ids,) = ctx.saved_tensors
+        p, seed, sid, V, D, B, has_add = ctx.key
+        dout = _f32c(dout)
+        R = ids.numel()
+        weight = ctx.weight
+        need_w, need_add = ctx.needs_input_grad[1], has_add and ctx.needs_input_grad[2]
+        dw_ret = None
+        target = None
+        if need_w:
+            g = weight.grad
+            if getattr(weight, "grad_inplace", False) and g is not None and g.is_cuda and g.dtype == torch.float32 \
+                    and g.is_contiguous() and g.shape == weight.shape:
+                target = g                      # accumulated in place; autograd gets no gradient for the weight
+            else:
+                target = dw_ret = torch.zeros((V, D), dtype=torch.float32, device=dout.device)
+        d_add = torch.empty((B, D), dtype=torch.float32, device=dout.device) if need_add else None
+        if target is not None or d_add is not None:
+            ws = _ws(L.gtg_embed_dropout_bwd_workspace_bytes(R, D, B if need_add else 0), dout.device)
+            check(L.gtg_embed_dropout_bwd(ptr(dout), ptr(ids), R, V, D, p, seed, sid, ptr(target), ptr(d_add),
+                                          B if need_add else 0, ptr(ws), ws.numel(), stream_ptr()), "gtg_embed_dropout_bwd")
+        return None, dw_ret, d_add, None
+
+
+def embed_dropout(ids, weight, p: float = 0.0, add=None):
+    """(T, B, D) = dropout_p(weight[ids]) + add[None]; see EmbedDropoutFn."""
+    return EmbedDropoutFn.apply(ids, weight, add, float(p))
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) in training mode (text_vae.py:64): y = x * keep / (1 - p), the mask regenerated in backward."""
+
+    @staticmethod
+    @_on_tensor_device
+    def forward(ctx, x, p):
+        x = _f32c(x)
+        if x.numel() % 4:
+            raise _lib.GtgError("dropout: the element count must be a multiple of 4")
+        y = torch.empty_like(x)
+        seed, sid = _rng_key()
+        check(_lib.lib().gtg_dropout(ptr(x), x.numel(), float(p), seed, sid, ptr(y), stream_ptr()), "gtg_dropout")
+        ctx.key = (float(p), seed, sid)
+        return y
+
+    @staticmethod
+    @_on_tensor_device
+    def backward(ctx, dy):
+        p, seed, sid = ctx.key
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        check(_lib.lib().gtg_dropout(ptr(dy), dy.numel(), p, seed, sid, ptr(dx), stream_ptr()), "gtg_dropout")
+        return dx, None
+
+
+def dropout(x, p: float, training: bool = True):
+    """x when not training or p == 0, else DropoutFn."""
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p))

@@ -1,9 +1,9 @@
 """Training step of the joint graph+text VAE (gtvae.py:95-126 driven as train.py:302-314 drives it) with
 the optimiser and the data-parallel exchange of the graph-only fast path.
 
-The forward and backward run through the GTVAE module (HIP kernels for the graph half and for the
-vocabulary projection + cross-entropy, stock PyTorch-ROCm LSTMs and embeddings in between, autograd to
-connect them).  What this class adds around the module:
+The forward and backward run through the GTVAE module (HIP kernels for the graph half, the LSTM
+recurrences, the embedding lookup / dropout / word noise and the vocabulary projection + cross-entropy;
+autograd connects them, and the three small Linear layers hgen, z2emb, zg_* stay torch.nn.Linear).  What this class adds around the module:
 
 * every parameter and every gradient lives in ONE flat fp32 buffer each (the module's parameters are views
   into it), so the optimiser is a single ``gtg_adam_step`` launch over all 65 M+ parameters (train.py:290:
@@ -98,6 +98,10 @@ class JointTrainer:
                 self.p[k] = view
                 self.g[k] = self.flat_g[o:o + n].view(shape)
                 named[k].grad = self.g[k]                 # autograd accumulates in place into the flat buffer
+        # the embedding's gradient is scatter-added straight into its rows of the flat buffer (functional.
+        # EmbedDropoutFn); autograd then sees no gradient for it, so its hook below never fires and the bucket it
+        # lives in (the last one) is launched after backward, when the scatter-adds have been enqueued
+        named["text_vae.embed.weight"].grad_inplace = True
         self.buckets = GradBuckets(self.flat_g, bounds, group)
         self.world = self.buckets.world
 

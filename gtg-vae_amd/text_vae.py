@@ -2,14 +2,14 @@
 
 Mirrors /root/reference/src/text_vae.py:22-132 (``TextModel``, ``DAE``): same
 sub-module names and shapes, hence the same ``state_dict`` keys
-(``embed, proj, E, G, hgen, z2emb``).  Embeddings run on stock PyTorch-ROCm
-kernels.  The LSTMs keep their parameters in ``nn.LSTM`` modules (same
-``state_dict`` keys) but on a GPU, in the 16-bit-pipe matrix modes (the default
-scaled two-plane fp16 one, the three-plane bf16 one and plain bf16), their
-forward and backward run through the library's own recurrence
-(``functional.lstm``: one fused product + cell launch per time step, the two
-directions of the encoder on two streams); the fp32 matrix mode and sizes the
-recurrence does not take use the stock module.  The vocabulary projection with its cross-entropy and arg-max -- most
+(``embed, proj, E, G, hgen, z2emb``).  On a GPU the embedding lookup with its
+dropout (and the decoder's added latent row), its scatter-add backward, the
+output dropout and the word-drop noise are library kernels (``functional.
+embed_dropout``, ``dropout``, ``word_drop``).  The LSTMs keep their parameters in ``nn.LSTM`` modules (same
+``state_dict`` keys) but on a GPU their forward and backward run through the
+library's own recurrence in every matrix mode (``functional.lstm``: one fused
+product + cell launch per time step, the two directions of the encoder on two
+streams); there is no vendor-LSTM path on the GPU.  The vocabulary projection with its cross-entropy and arg-max -- most
 of the branch's arithmetic, 2*1024*vocab per token -- has a HIP path of its
 own, ``decode_loss``: it skips the pad tokens' rows in all three GEMMs and
 never holds more than one copy of the logits.
@@ -59,15 +59,22 @@ class DAE(TextModel):
         return owned_stream(device, "lstm")
 
     def run_lstm(self, mod, emb, hidden=None, need_output=True):
-        """``mod(emb, hidden)`` for a one-layer ``nn.LSTM``: through functional.lstm, one call per direction, when
-        the input is fp32 on a GPU, the matrix mode is one of the bf16-pipe ones and the sizes fit; else the stock
-        module.  With ``need_output`` False the (T, B, dirs*H) output is not assembled (None is returned for it)."""
+        """``mod(emb, hidden)`` for a one-layer ``nn.LSTM``.  On a GPU there is ONE path, the library's recurrence
+        (functional.lstm, one call per direction) in every matrix mode -- the mode picks the pipe of the four
+        products over all time steps, the per-step products run on split 16-bit planes at fp32 accuracy (two fp16
+        planes in the default mode, three bf16 planes otherwise, the fp32 mode included) -- and sizes it does not
+        take are an error, not a detour through the vendor's LSTM.  A module on the CPU (the tests' mirror of the
+        reference's DAE) runs the stock module.  With ``need_output`` False the (T, B, dirs*H) output is not
+        assembled (None is returned for it)."""
+        if not emb.is_cuda:
+            return mod(emb, hidden)
         T, B, I = emb.shape
         H = mod.hidden_size
         mode = _lib.matrix_mode(getattr(self, "matrix_mode", None))
-        if not (emb.is_cuda and emb.dtype == torch.float32 and mode != _lib.MATRIX_MODES["f32"] and
-                mod.num_layers == 1 and Fn.lstm_applies(T, B, I, H)):
-            return mod(emb, hidden)
+        if emb.dtype != torch.float32 or mod.num_layers != 1 or not Fn.lstm_applies(T, B, I, H):
+            raise _lib.GtgError("the LSTM recurrence takes fp32 input, one layer, input size a multiple of 4 and hidden "
+                                "size a multiple of 64 (got %s, %d layers, I=%d, H=%d)" % (emb.dtype, mod.num_layers, I, H))
+
         def one_direction(d):
             sfx = "_l0_reverse" if d else "_l0"
             h0 = hidden[0][d] if hidden is not None else None
@@ -99,15 +106,29 @@ class DAE(TextModel):
             output = outs[0] if len(outs) == 1 else torch.cat(outs, 2)
         return output, (torch.stack(hn), torch.stack(cn))
 
-    def encode(self, input):
+    def _embed(self, input, add=None):
+        """self.drop(self.embed(input)) (+ add, a (B, 512) row per sentence broadcast over time): on a GPU one
+        library kernel (lookup, dropout mask regenerated in the backward, the add) with an ordered scatter-add as
+        backward; the stock modules for a model left on the CPU."""
+        w = self.embed.weight
+        if w.is_cuda:
+            return Fn.embed_dropout(input, w, self.drop.p if self.training else 0.0, add)
         emb = self.drop(self.embed(input))
+        return emb if add is None else emb + add
+
+    def _drop(self, x):
+        """self.drop(x): the library's dropout on a GPU (mask regenerated in the backward, never stored)."""
+        return Fn.dropout(x, self.drop.p, self.training) if x.is_cuda else self.drop(x)
+
+    def encode(self, input):
+        emb = self._embed(input)
         _, (ht, _) = self.run_lstm(self.E, emb, need_output=False)
         return self.hgen(torch.cat([ht[-2], ht[-1]], 1))
 
     def decode(self, z, input, hidden=None):
-        emb = self.drop(self.embed(input)) + self.z2emb(z)
+        emb = self._embed(input, self.z2emb(z))
         output, hidden = self.run_lstm(self.G, emb, hidden)
-        output = self.drop(output)
+        output = self._drop(output)
         logits = self.proj(output.view(-1, output.size(-1)))
         return logits.view(output.size(0), output.size(1), -1), hidden
 
@@ -119,9 +140,9 @@ class DAE(TextModel):
         attribute if one was set, else the package default."""
         if matrix_mode is None:
             matrix_mode = getattr(self, "matrix_mode", None)
-        emb = self.drop(self.embed(input)) + self.z2emb(z)
+        emb = self._embed(input, self.z2emb(z))
         output, hidden = self.run_lstm(self.G, emb, hidden)
-        output = self.drop(output)
+        output = self._drop(output)
         loss, pred = Fn.proj_ce(output.reshape(-1, output.size(-1)), self.proj.weight, self.proj.bias,
                                 targets.reshape(-1), self.padidx, matrix_mode)
         return loss.view(targets.size()), pred.view(targets.size()), hidden

@@ -305,10 +305,19 @@ int gtg_proj_ce_bwd(const float* W, const float* gloss, const int32_t* rowmap, c
  * sequence, of h_n and of c_n, each may be NULL -- and writes dw_ih (4H, I),
  * dw_hh (4H, H), db (4H) (the gradient of b_ih and of b_hh alike), and, where
  * not NULL, dx (T, B, I), dh0, dc0 (B, H).
- * I must be a multiple of 4 and H of 64 (GTG_ERR_UNSUPPORTED otherwise).  The
- * recurrent products always run on three bf16 planes per operand with fp32
- * accumulation (fp32-level error); matrix_mode selects the pipe of the large
- * products outside the recurrence (input projection, dW, dx). */
+ * I must be a multiple of 4 and H of 64 (GTG_ERR_UNSUPPORTED otherwise).
+ * matrix_mode selects the pipe of the four large products outside the
+ * recurrence (input projection, dW_ih, dW_hh, dx).  The per-step recurrent
+ * products h_{t-1} W_hh^T and dG_t W_hh run on split 16-bit planes at fp32-level
+ * error in EVERY mode: with GTG_MATRIX_F16X2 and H <= 1024 on two scaled fp16
+ * planes per operand and three products (h at the fixed scale 2^13, a given
+ * initial state and the gate gradients scaled per row by the kernel that writes
+ * them, W_hh by one power of two found by a pass over it); otherwise --
+ * GTG_MATRIX_F32, _BF16X3, _BF16, and F16X2 with H > 1024 -- on three bf16 planes
+ * per operand and six products.  There is no fp32-MFMA recurrence.
+ * The step kernel holds 68 KB of static LDS (a 64 x 64 fp32 tile per wave for the
+ * K-split reduction): more than the 64 KB of earlier CDNA parts, so this file
+ * builds for gfx950 (160 KB per CU) only. */
 size_t gtg_lstm_fwd_workspace_bytes(int T, int B, int I, int H);
 int gtg_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                  const float* h0, const float* c0, int T, int B, int I, int H, int reverse, float* hs, float* cs,
@@ -318,6 +327,44 @@ int gtg_lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const flo
                  const float* cs, const float* gates, const float* d_hs, const float* d_hT, const float* d_cT, int T,
                  int B, int I, int H, int reverse, float* dx, float* dw_ih, float* dw_hh, float* db, float* dh0,
                  float* dc0, int matrix_mode, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- text branch: word drop, embedding lookup + dropout, dropout -------------
+ * Randomness in these calls is counter-based (Philox4x32-10): whether an element is kept is a pure function of
+ * (seed, stream_id, element index), so a backward call given the forward call's (seed, stream_id) regenerates
+ * the forward's mask and no mask is stored.  Use a fresh stream_id per forward call.  The sequences are not
+ * PyTorch's or numpy's; the distribution (keep with probability 1 - p, kept values scaled by 1 / (1 - p)) is.
+ *
+ * gtg_word_drop replaces noise.word_drop (src/noise.py:12-22, reached from src/text_vae.py:70 with p = 0.3):
+ * tokens, out (T, B) int64, time-major; per sentence (column) every token but the first is dropped with
+ * probability p, the kept ones move up in order, the tail is filled with padidx.  `keep` (T, B) uint8,
+ * nullable: an explicit keep mask instead of the random one (row 0 is kept either way).  out must not alias
+ * tokens.
+ *
+ * gtg_embed_dropout_fwd replaces self.drop(self.embed(input)) (src/text_vae.py:56) and, with `add`,
+ * self.drop(self.embed(input)) + self.z2emb(z) (src/text_vae.py:62): out[r, :] = drop(table[ids[r], :])
+ * + add[r mod add_rows, :].  table (vocab, dim), ids (rows) int64, add (add_rows, dim) nullable, out (rows, dim);
+ * dim a multiple of 4.  An id outside [0, vocab) sets *err (nullable int32, never cleared by the library) and
+ * reads row 0.
+ * gtg_embed_dropout_bwd replaces the backward of both (nn.Embedding's scatter-add, src/text_vae.py:35):
+ * dtable[id, :] += sum over the rows r with ids[r] == id of drop'(dout[r, :]), the rows of an id taken in a fixed
+ * order (ascending inside groups of 256 rows, then ascending groups): bit-reproducible, no float atomics.
+ * dtable is accumulated into, not overwritten; rows whose id lies outside the table are skipped; at most
+ * 262 144 rows per call.  d_add (add_rows, dim), nullable: the gradient of `add`, the sum of dout over the rows
+ * that share an add row (no dropout on that path; overwritten, not accumulated).  dtable may be NULL when only
+ * d_add is wanted.
+ *
+ * gtg_dropout replaces self.drop(output) (src/text_vae.py:64) and its backward, which is the same map applied to
+ * the gradient: y[i] = keep(i) ? x[i] / (1 - p) : 0; count a multiple of 4; y may alias x. */
+int gtg_word_drop(const int64_t* tokens, int T, int B, int64_t padidx, float p, uint64_t seed, uint64_t stream_id,
+                  const uint8_t* keep, int64_t* out, void* stream);
+int gtg_embed_dropout_fwd(const float* table, const int64_t* ids, int64_t rows, int64_t vocab, int dim, float p,
+                          uint64_t seed, uint64_t stream_id, const float* add, int add_rows, float* out, int32_t* err,
+                          void* stream);
+size_t gtg_embed_dropout_bwd_workspace_bytes(int64_t rows, int dim, int add_rows);
+int gtg_embed_dropout_bwd(const float* dout, const int64_t* ids, int64_t rows, int64_t vocab, int dim, float p,
+                          uint64_t seed, uint64_t stream_id, float* dtable, float* d_add, int add_rows, void* ws,
+                          size_t ws_bytes, void* stream);
+int gtg_dropout(const float* x, int64_t count, float p, uint64_t seed, uint64_t stream_id, float* y, void* stream);
 
 /* ---- optimiser -------------------------------------------------------------
  * Replaces optim.Adam(lr, betas=(0.5, 0.999)).step() (src/train.py:290,314)

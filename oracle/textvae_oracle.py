@@ -23,10 +23,16 @@ evaluation mode (dropout and word noise off, text_vae.py:55-57, 62-64, 69-72):
                      the line the reference leaves commented out, gtvae.py:124, is
                      restored by ``train_graph_recon``)
 * ``forward_1``   <- GTVAE.forward_1 (gtvae.py:77-91)
+* ``word_drop``   <- noise.word_drop (/root/reference/src/noise.py:12-22) with the
+                     keep flags it draws per sentence (noise.py:16) passed in
+* ``embed_dropout`` <- self.drop(self.embed(input)) [+ self.z2emb(z)]
+                     (text_vae.py:56, 62) with the dropout mask passed in
 
 Pinned: tests/test_oracle_textvae.py checks encode / decode / loss_rec /
 accuracy against tests/golden/textvae_golden.npz, which was produced by running
-the reference's own text_vae.DAE (tests/golden/make_text_golden.py).
+the reference's own text_vae.DAE (tests/golden/make_text_golden.py), and
+word_drop against tests/golden/noise_golden.npz, produced by running the
+reference's own noise.word_drop (tests/golden/make_noise_golden.py).
 """
 from __future__ import annotations
 
@@ -128,3 +134,31 @@ def forward_1(params, inputs, targets, eps, padidx: int = 0):
     logits, _ = decode(params, z, inputs, "text_vae.")
     rec = loss_rec(logits, targets, padidx).mean()
     return kl + rec, accuracy(logits.detach(), targets, padidx)
+
+
+def word_drop(x, keep, padidx: int):
+    """noise.word_drop (noise.py:12-22) for token ids x (T, B) with the keep flags of noise.py:16 given as
+    ``keep`` (T, B) bool: per sentence the first token is always kept (noise.py:17), kept tokens stay in order
+    (noise.py:18) and the sentence is padded back to its length with padidx (noise.py:19)."""
+    x = torch.as_tensor(x)
+    keep = torch.as_tensor(keep).bool()
+    cols = []
+    for i in range(x.size(1)):
+        words = x[:, i].tolist()
+        k = keep[:, i].tolist()
+        k[0] = True
+        sent = [w for j, w in enumerate(words) if k[j]]
+        sent += [padidx] * (len(words) - len(sent))
+        cols.append(sent)
+    return torch.tensor(cols, dtype=torch.long).t().contiguous()
+
+
+def embed_dropout(table, ids, keep=None, p: float = 0.0, add=None):
+    """drop(table[ids]) (+ add broadcast over time), text_vae.py:56 / :62, with dropout's keep mask (T, B, D)
+    given: kept values are scaled by 1 / (1 - p) as nn.Dropout does in training mode."""
+    out = table[ids]
+    if keep is not None:
+        out = out * keep.to(out.dtype) / (1.0 - p)
+    if add is not None:
+        out = out + add.unsqueeze(0)
+    return out

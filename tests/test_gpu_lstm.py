@@ -31,7 +31,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2", "f32"])
 @pytest.mark.parametrize("T,B,I,H,reverse,init", CASES)
 def test_lstm_forward_and_backward_match_oracle(T, B, I, H, reverse, init, mode):
     from gtg_vae_amd import functional as Fn
@@ -159,7 +159,8 @@ def test_lstm_final_state_only_gradient():
 
 def test_module_routes_through_the_hip_recurrence_and_matches_stock_lstm():
     """DAE.run_lstm: same results as the stock nn.LSTM module it wraps (both directions, given hidden state),
-    and the stock module is what runs in the fp32 matrix mode."""
+    in the default matrix mode and in the fp32 one (the library's recurrence runs in both: there is no vendor-LSTM
+    path on the GPU), and sizes the recurrence does not take are an error."""
     from gtg_vae_amd.text_vae import DAE
 
     torch.manual_seed(0)
@@ -172,8 +173,15 @@ def test_module_routes_through_the_hip_recurrence_and_matches_stock_lstm():
         assert out.shape == want_out.shape and h.shape == want_h.shape and c.shape == want_c.shape
         assert _relerr(out, want_out) < 1e-5 and _relerr(h, want_h) < 1e-5 and _relerr(c, want_c) < 1e-5
     m.matrix_mode = "f32"
-    out, _ = m.run_lstm(m.G, emb, None)
-    assert torch.equal(out, m.G(emb)[0])
+    out, (h, _) = m.run_lstm(m.G, emb, None)
+    want_out, (want_h, _) = m.G(emb)
+    assert _relerr(out, want_out) < 1e-5 and _relerr(h, want_h) < 1e-5
+    assert not torch.equal(out, want_out)          # not the stock module's kernels
+    from gtg_vae_amd import _lib
+
+    odd = torch.nn.LSTM(512, 96, 1).cuda()          # hidden size not a multiple of 64
+    with pytest.raises(_lib.GtgError):
+        m.run_lstm(odd, emb, None)
 
 
 def test_lstm_bf16_mode_stays_close():

@@ -65,3 +65,18 @@ def test_explicit_recurrence_equals_nn_lstm_with_gradients(reverse):
     o2.square().sum().backward()
     for a, b in zip(w, w2):
         assert torch.allclose(a.grad, b.grad, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["small", "batch", "long", "keep_all", "drop_most"])
+def test_word_drop_oracle_reproduces_the_reference(tag):
+    """noise_golden.npz holds tokens, the keep flags the reference drew (noise.py:16) and its output."""
+    import os
+
+    import numpy as np
+
+    from oracle import textvae_oracle as TO
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "noise_golden.npz"))
+    pad = int(g[tag + "__meta"][0])
+    got = TO.word_drop(g[tag + "__x"], g[tag + "__keep"], pad)
+    assert np.array_equal(got.numpy(), g[tag + "__out"])
