@@ -66,7 +66,7 @@ _SIGS = {
     "gtg_word_drop": (c_int, [_P, c_int, c_int, c_int64, c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P, _P]),
     "gtg_embed_dropout_fwd": (c_int, [_P, _P, c_int64, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint64, _P, c_int,
                                       _P, _P, _P]),
-    "gtg_embed_dropout_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "gtg_embed_dropout_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
     "gtg_embed_dropout_bwd": (c_int, [_P, _P, c_int64, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P,
                                       c_int, _P, c_size_t, _P]),
     "gtg_dropout": (c_int, [_P, c_int64, c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),

@@ -978,10 +978,10 @@ int gtg_embed_dropout_fwd(const float* table, const int64_t* ids, int64_t rows, 
     return embed_dropout_fwd(table, ids, rows, vocab, dim, p, seed, stream_id, add, add_rows, out, err, (hipStream_t)stream);
 }
 
-size_t gtg_embed_dropout_bwd_workspace_bytes(int64_t rows, int dim, int add_rows)
+size_t gtg_embed_dropout_bwd_workspace_bytes(int64_t rows, int64_t vocab, int dim, int add_rows)
 {
     Carver c(nullptr, 0);
-    c.take<char>(embed_dropout_bwd_workspace(rows, dim));
+    c.take<char>(embed_dropout_bwd_workspace(rows, vocab, dim));
     if (add_rows > 0) c.take<char>(colsum_workspace(rows / add_rows, add_rows * dim));
     return c.off;
 }
@@ -999,12 +999,12 @@ int gtg_embed_dropout_bwd(const float* dout, const int64_t* ids, int64_t rows, i
                 "dout, dtable, d_add and ws must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     Carver c(ws, ws_bytes);
-    char* scatter_ws = c.take<char>(embed_dropout_bwd_workspace(rows, dim));
+    char* scatter_ws = c.take<char>(embed_dropout_bwd_workspace(rows, vocab, dim));
     float* cs = d_add ? reinterpret_cast<float*>(c.take<char>(colsum_workspace(rows / add_rows, add_rows * dim))) : nullptr;
     if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_embed_dropout_bwd: workspace too small");
     if (dtable)
         GTG_TRY(embed_dropout_bwd(dout, ids, rows, vocab, dim, p, seed, stream_id, dtable, scatter_ws,
-                                  embed_dropout_bwd_workspace(rows, dim), s));
+                                  embed_dropout_bwd_workspace(rows, vocab, dim), s));
     if (d_add)  // the added rows are shared by the rows r, r + add_rows, ...: column sums of dout seen as (rows / add_rows, add_rows * dim)
         GTG_TRY(colsum(dout, rows / add_rows, add_rows * dim, add_rows * dim, cs, d_add, s));
     return GTG_OK;

@@ -303,7 +303,7 @@ int word_drop(const int64_t* x, int T, int B, int64_t padidx, float p, unsigned 
               const uint8_t* keep, int64_t* out, hipStream_t s);
 int embed_dropout_fwd(const float* table, const int64_t* ids, int64_t R, int64_t V, int D, float p, unsigned long long seed,
                       unsigned long long sid, const float* add, int B_add, float* out, int32_t* err, hipStream_t s);
-size_t embed_dropout_bwd_workspace(int64_t R, int D);
+size_t embed_dropout_bwd_workspace(int64_t R, int64_t V, int D);
 int embed_dropout_bwd(const float* dout, const int64_t* ids, int64_t R, int64_t V, int D, float p, unsigned long long seed,
                       unsigned long long sid, float* dtable, void* ws, size_t ws_bytes, hipStream_t s);
 int dropout_map(const float* x, int64_t n, float p, unsigned long long seed, unsigned long long sid, float* y, hipStream_t s);

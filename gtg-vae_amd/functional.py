@@ -587,7 +587,7 @@ class EmbedDropoutFn(torch.autograd.Function):
                 target = dw_ret = torch.zeros((V, D), dtype=torch.float32, device=dout.device)
         d_add = torch.empty((B, D), dtype=torch.float32, device=dout.device) if need_add else None
         if target is not None or d_add is not None:
-            ws = _ws(L.gtg_embed_dropout_bwd_workspace_bytes(R, D, B if need_add else 0), dout.device)
+            ws = _ws(L.gtg_embed_dropout_bwd_workspace_bytes(R, V, D, B if need_add else 0), dout.device)
             check(L.gtg_embed_dropout_bwd(ptr(dout), ptr(ids), R, V, D, p, seed, sid, ptr(target), ptr(d_add),
                                           B if need_add else 0, ptr(ws), ws.numel(), stream_ptr()), "gtg_embed_dropout_bwd")
         return None, dw_ret, d_add, None

@@ -346,8 +346,10 @@ int gtg_lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const flo
  * dim a multiple of 4.  An id outside [0, vocab) sets *err (nullable int32, never cleared by the library) and
  * reads row 0.
  * gtg_embed_dropout_bwd replaces the backward of both (nn.Embedding's scatter-add, src/text_vae.py:35):
- * dtable[id, :] += sum over the rows r with ids[r] == id of drop'(dout[r, :]), the rows of an id taken in a fixed
- * order (ascending inside groups of 256 rows, then ascending groups): bit-reproducible, no float atomics.
+ * dtable[id, :] += sum over the rows r with ids[r] == id of drop'(dout[r, :]), the rows of an id added in a fixed
+ * order (a sum per group of 128 consecutive rows, then the group sums in ascending order; a list of eight or more
+ * addends is cut into four contiguous parts summed side by side and joined in part order): the result depends on
+ * the inputs alone, bit for bit -- no float atomics.
  * dtable is accumulated into, not overwritten; rows whose id lies outside the table are skipped; at most
  * 262 144 rows per call.  d_add (add_rows, dim), nullable: the gradient of `add`, the sum of dout over the rows
  * that share an add row (no dropout on that path; overwritten, not accumulated).  dtable may be NULL when only
@@ -360,7 +362,7 @@ int gtg_word_drop(const int64_t* tokens, int T, int B, int64_t padidx, float p, 
 int gtg_embed_dropout_fwd(const float* table, const int64_t* ids, int64_t rows, int64_t vocab, int dim, float p,
                           uint64_t seed, uint64_t stream_id, const float* add, int add_rows, float* out, int32_t* err,
                           void* stream);
-size_t gtg_embed_dropout_bwd_workspace_bytes(int64_t rows, int dim, int add_rows);
+size_t gtg_embed_dropout_bwd_workspace_bytes(int64_t rows, int64_t vocab, int dim, int add_rows);
 int gtg_embed_dropout_bwd(const float* dout, const int64_t* ids, int64_t rows, int64_t vocab, int dim, float p,
                           uint64_t seed, uint64_t stream_id, float* dtable, float* d_add, int add_rows, void* ws,
                           size_t ws_bytes, void* stream);
