@@ -210,6 +210,28 @@ def mst_bench(device, G=65536, N=64, reps=5, cpu=True):
                         "algorithmic_bytes_per_graph": bytes_per_graph}}
     if cpu:
         res["cpu_baseline"] = mst_cpu_baseline(rows_host, N)
+    # the same read-out at the reference's default size (N = 10, train.py:544: four graphs share a wavefront) and
+    # at N = 32, same number of graphs, same distribution
+    other = {}
+    for n2 in (10, 32):
+        m2 = n2 * (n2 + 1) // 2
+        r2 = torch.rand((G, m2), generator=g)
+        iu2 = torch.triu_indices(n2, n2)
+        r2[:, torch.nonzero(iu2[0] == iu2[1]).flatten()] = 0.3 + 0.7 * torch.rand((G, n2), generator=g)
+        r2 = r2.to(device)
+        mst_graph_batched(r2, n2)
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        for _ in range(reps):
+            mst_graph_batched(r2, n2)
+        torch.cuda.synchronize()
+        rep2 = [r for r in _lib.profile_report() if r[0] == "mst_triu"]
+        _lib.profile_enable(False)
+        ms2 = rep2[0][5] / rep2[0][4]
+        b2 = 4 * m2 + 4 * (2 * (n2 - 1) + 1)
+        other["N=%d" % n2] = {"ms": ms2, "graphs_per_s": G / (ms2 * 1e-3), "GB_per_s": G * b2 / (ms2 * 1e-3) / 1e9,
+                              "algorithmic_bytes_per_graph": b2}
+    res["other_sizes"] = other
     return res
 
 

@@ -296,6 +296,147 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Graphs of at most 16 nodes (the reference's default is 10, train.py:544): FOUR graphs per wavefront, one per
+// DPP row of 16 lanes.  Lane (s, j) = (lane / 16, lane % 16) owns vertex j of the wave's s-th graph.  A row
+// reduction needs no step across rows -- four single-instruction DPP steps (two inside quads, half-row mirror,
+// row mirror) leave every lane holding its own row's result -- so neither the maximum nor the chosen vertex ever
+// goes through a scalar register: the arg-max is a float max over the row followed by an unsigned min over
+// (lane holds the max ? j : 16), and the chosen vertex m is a per-lane value.  Because m differs between the
+// four graphs of a wave, T[j][m] cannot come from an indexed register; each graph's matrix is kept as a full
+// 16 x 17 tile in LDS (rebuilt from the triangular row when the input is triangular) and the round reads one
+// element of it.  Same semantics, same output as mst_kernel.
+constexpr int SMALL_N = 16;
+constexpr int SMALL_LD = SMALL_N + 1;
+constexpr int SMALL_TRI = SMALL_N * (SMALL_N + 1) / 2;
+
+__device__ __forceinline__ float row16_max(float v)
+{
+    float t;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "=&v"(t) : "v"(v));
+    return t;
+}
+
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v)
+{
+    unsigned t;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "=&v"(t) : "v"(v));
+    return t;
+}
+
+template <bool TRIU>
+__global__ __launch_bounds__(WAVES * 64) void mst_small_kernel(const float* __restrict__ in, int64_t G, int n,
+                                                                int32_t* __restrict__ edges, int32_t* __restrict__ count)
+{
+    // per wave: the four graphs' input as it lies in memory (4 * per floats, contiguous), then four 16 x 17 tiles
+    constexpr int RAW = 4 * (TRIU ? SMALL_TRI : SMALL_N * SMALL_N);
+    constexpr int PER_WAVE = RAW + 4 * SMALL_N * SMALL_LD;
+    __shared__ __attribute__((aligned(16))) float lds[WAVES * PER_WAVE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane >> 4, j = lane & 15;
+    const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+    const int per = TRIU ? n * (n + 1) / 2 : n * n;   // floats per graph in memory
+    float* raw = lds + wave * PER_WAVE;
+    float* tile = raw + RAW + sub * (SMALL_N * SMALL_LD);
+    const int jc = (j < n) ? j : 0;  // lanes past n read vertex 0's row; their values are never used
+    const int cj = jc * n - (jc * (jc - 1)) / 2 - jc;
+
+    for (int64_t q = (int64_t)blockIdx.x * WAVES + wave; q * 4 < G; q += nwaves) {
+        const int64_t g = q * 4 + sub;
+        const bool valid = g < G;
+        // the wave's four graphs are contiguous in memory: one coalesced copy
+        const int64_t left = G - q * 4;
+        const int total = (int)(left < 4 ? left : 4) * per;
+        const float* src = in + q * 4 * per;
+        for (int idx = lane; idx < total; idx += 64) raw[idx] = src[idx];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const float* mine = raw + sub * per;
+        // lane (s, j) writes row j of its graph's tile: tile[j][c] = T[j][c]
+        float diag = 0.f;
+        if (valid) {
+            for (int c = 0; c < n; ++c) {   // wave-uniform trip count
+                float v;
+                if (TRIU) {
+                    // U[min(j,c)][max(j,c)]: the right one of the two candidate offsets is the smaller (see mst_kernel)
+                    const int cc = c * n - (c * (c - 1)) / 2 - c;
+                    v = mine[min(jc + cc, cj + c)];
+                } else {
+                    v = mine[jc * n + c];
+                }
+                tile[jc * SMALL_LD + c] = v;   // lanes past n rewrite row 0 with the same values
+                if (c == jc) diag = v;
+            }
+            if (TRIU) diag = (diag + diag) - diag;   // U + U^T - diag(U), graph_vae.py:67-69 (inf -> NaN, huge -> inf)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        const unsigned long long pres_all = __ballot(valid && j < n && diag > 0.5f);
+        const unsigned pres = (unsigned)(pres_all >> (16 * sub)) & 0xffffu;   // this graph's present set
+        const int V = __popc(pres);
+        const int root = V ? __ffs(pres) - 1 : 0;
+        const int last = V ? 31 - __clz(pres) : 0;
+        const bool pj = (pres >> j) & 1u;
+
+        // w as in mst_kernel (NaN = visited or absent, -2^63 = not reached); the root starts at +2^63, the
+        // reference's weights[0] = +maxsize, so that the first round selects it through the common path
+        float w = pj ? (j == root ? -NEG_SENTINEL : NEG_SENTINEL) : __builtin_nanf("");
+        int parent = root;
+        // every graph of the wave runs its own V - 1 rounds; the wave loops until the largest is done
+        for (int r = 0; __ballot(r < V - 1) != 0ull; ++r) {
+            const bool live = r < V - 1;
+            const float mx = row16_max(w);
+            const unsigned first = row16_min_u32((w == mx) ? (unsigned)j : 16u);
+            // nothing reached yet -> Python's index -1 = the last present vertex
+            const int m = (__float_as_int(mx) == __float_as_int(NEG_SENTINEL)) ? last : (int)first;
+            const float t = tile[jc * SMALL_LD + m];   // m <= 16: column 16 is the tile's pad (a finished graph's rows)
+            if (live) {
+                if (j == m) w = __builtin_nanf("");
+                const bool upd = (t != 0.f) && (t > w);
+                w = upd ? t : w;
+                parent = upd ? m : parent;
+            }
+        }
+
+        if (valid) {
+            int32_t* eout = edges + g * 2 * (n - 1);
+            if (pj && j != root) {
+                const int li = __popc(pres & ((1u << j) - 1u));
+                eout[2 * (li - 1)] = parent;
+                eout[2 * (li - 1) + 1] = j;
+            }
+            const int used = V > 0 ? V - 1 : 0;
+            if (j >= used && j < n - 1) {
+                eout[2 * j] = -1;
+                eout[2 * j + 1] = -1;
+            }
+            if (j == 0) count[g] = used;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next quad's copy overwrites raw and the tiles
+    }
+}
+
 }  // namespace
 
 static int num_cus()
@@ -324,6 +465,17 @@ static int mst_launch(bool triu, const float* in, int64_t G, int n, int32_t* edg
     const int64_t resident = (int64_t)num_cus() * (triu ? 4 : 2);
     if (blocks > resident) blocks = resident;
     ProfScope prof(s, triu ? "mst_triu" : "mst_full", G, n, 0);
+    if (n <= SMALL_N) {
+        // four graphs per wavefront, 16 per block; 7.5 KB (triangular) / 8.4 KB (full) of LDS per wave
+        int64_t small_blocks = (G + 4 * WAVES - 1) / (4 * WAVES);
+        const int64_t small_resident = (int64_t)num_cus() * 4;
+        if (small_blocks > small_resident) small_blocks = small_resident;
+        if (triu)
+            hipLaunchKernelGGL((mst_small_kernel<true>), dim3((unsigned)small_blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+        else
+            hipLaunchKernelGGL((mst_small_kernel<false>), dim3((unsigned)small_blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+        return check_launch("mst_small_kernel");
+    }
     if (triu && n == 64)
         hipLaunchKernelGGL((mst_kernel<true, true, true>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
     else if (triu && n >= 40)

@@ -47,7 +47,7 @@ def test_golden_triu_rows_bit_exact(gold):
         assert int(c[0]) == len(want) and np.array_equal(e[0, : len(want)], want), name
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 10, 31, 32, 33, 39, 40, 48, 63, 64])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 10, 13, 16, 17, 31, 32, 33, 39, 40, 48, 63, 64])
 def test_random_batches_match_c_oracle(n):
     from oracle import c_mst
     from gtg_vae_amd import mst_graph_batched
