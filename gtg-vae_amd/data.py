@@ -165,8 +165,84 @@ def pad_tokens(token_lists, pad: int = 0) -> Optional[torch.Tensor]:
     return torch.from_numpy(out)
 
 
+class PackedGraphs:
+    """A list of GraphData packed once into a few flat host tensors, so that a batch is a handful of vectorised
+    gathers instead of a Python loop over its graphs (which is what makes per-batch collation the bottleneck of a
+    host-side loader: torch_geometric's collate, train.py:549, walks the batch's Data objects in Python too):
+    every graph's edge list with LOCAL node ids, concatenated, with start offsets and the owning graph of every
+    edge; the padded fp32 targets; gold-edge bit masks; node counts; token ids padded to the longest sentence
+    with their lengths.  ``batch(ids)`` returns exactly what ``collate([data[i] for i in ids], nmax)`` returns."""
+
+    def __init__(self, data_list: Sequence[GraphData], nmax: int):
+        self.data = list(data_list)
+        self.nmax, self.num_graphs = nmax, len(self.data)
+        lens = np.array([d.edge_index.shape[1] for d in self.data], dtype=np.int64)
+        start = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=start[1:])
+        self.edge_len = torch.from_numpy(lens)
+        self.edge_start = torch.from_numpy(start)
+        self.edges_local = (torch.cat([d.edge_index for d in self.data], dim=1) if self.data
+                            else torch.zeros((2, 0), dtype=torch.long)).contiguous()
+        self.adj_all = (torch.stack([d.adj32() for d in self.data]) if self.data
+                        else torch.zeros((0, nmax, nmax))).contiguous()
+        self.gold_bits = gold_bitmask([d.gold_edges for d in self.data], nmax)
+        self.num_nodes = torch.tensor([d.num_nodes for d in self.data], dtype=torch.int32)
+        self.edge_graph = torch.repeat_interleave(torch.arange(self.num_graphs, dtype=torch.int64), self.edge_len)
+        self.tokens = None
+        if self.data and all(d.tokens is not None for d in self.data):
+            self.tokens = pad_tokens([d.tokens for d in self.data])
+            self.token_len = torch.tensor([len(d.tokens) for d in self.data], dtype=torch.int64)
+        self.pinned = False
+
+    def __len__(self):
+        return self.num_graphs
+
+    def pin(self):
+        """Move the large arrays to page-locked memory, once: a batch of consecutive graphs (an unshuffled
+        loader's) is then made of views of pinned memory, and its host-to-device copy is an asynchronous DMA
+        with no per-batch pinning copy."""
+        if not self.pinned and torch.cuda.is_available():
+            self.adj_all, self.gold_bits, self.num_nodes = self.adj_all.pin_memory(), self.gold_bits.pin_memory(), \
+                self.num_nodes.pin_memory()
+            if self.tokens is not None:
+                self.tokens = self.tokens.pin_memory()
+            self.pinned = True
+        return self
+
+    def batch(self, ids) -> "GraphBatch":
+        ids = torch.as_tensor(ids, dtype=torch.int64)
+        B, n = int(ids.numel()), self.nmax
+        if B == 0:
+            return collate([], n)
+        a = int(ids[0])
+        if int(ids[-1]) - a == B - 1 and bool((ids == torch.arange(a, a + B)).all()):
+            # consecutive graphs: slices (views) of the packed arrays, one vectorised renumbering of the edges
+            b, s, e = a + B, int(self.edge_start[a]), int(self.edge_start[a + B])
+            ei = self.edges_local[:, s:e] + (self.edge_graph[s:e] - a) * n
+            dec_seq = None
+            if self.tokens is not None:
+                dec_seq = self.tokens[a:b, : int(self.token_len[a:b].max())].contiguous()
+            return GraphBatch(ei, torch.arange(B, dtype=torch.long).repeat_interleave(n), self.adj_all[a:b],
+                              [d.gold_edges for d in self.data[a:b]], [d.snts for d in self.data[a:b]], B, n,
+                              self.num_nodes[a:b], None, self.gold_bits[a:b], dec_seq=dec_seq)
+        lens = self.edge_len[ids]
+        # position of every edge of the batch in the packed list: the graph's start + 0..len-1
+        slot = torch.repeat_interleave(torch.arange(B, dtype=torch.int64), lens)          # batch slot of each edge
+        first = torch.cumsum(lens, 0) - lens                                               # where each graph's run begins
+        pos = self.edge_start[ids][slot] + (torch.arange(int(lens.sum()), dtype=torch.int64) - first[slot])
+        ei = self.edges_local[:, pos] + slot * n
+        idl = ids.tolist()
+        dec_seq = None
+        if self.tokens is not None:
+            dec_seq = self.tokens[ids][:, : int(self.token_len[ids].max())].contiguous()
+        return GraphBatch(ei.contiguous(), torch.arange(B, dtype=torch.long).repeat_interleave(n), self.adj_all[ids],
+                          [self.data[i].gold_edges for i in idl], [self.data[i].snts for i in idl], B, n,
+                          self.num_nodes[ids], None, self.gold_bits[ids], dec_seq=dec_seq)
+
+
 class DataLoader:
-    """Minimal stand-in for torch_geometric's DataLoader(dataset, batch_size) (train.py:549-550)."""
+    """Minimal stand-in for torch_geometric's DataLoader(dataset, batch_size) (train.py:549-550).  The dataset is
+    packed once (PackedGraphs); every batch is then assembled by vectorised gathers."""
 
     def __init__(self, dataset: Sequence[GraphData], batch_size: int, nmax: int = None, shuffle: bool = False, seed: int = 0):
         self.dataset = list(dataset)
@@ -174,16 +250,23 @@ class DataLoader:
         self.nmax = nmax if nmax is not None else (self.dataset[0].maxnode if self.dataset else 0)
         self.shuffle = shuffle
         self._rng = np.random.default_rng(seed)
+        self._packed = None
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
+    def packed(self) -> PackedGraphs:
+        if self._packed is None:
+            self._packed = PackedGraphs(self.dataset, self.nmax)
+        return self._packed
+
     def __iter__(self):
+        self.packed()
         order = np.arange(len(self.dataset))
         if self.shuffle:
             self._rng.shuffle(order)
         for i in range(0, len(order), self.batch_size):
-            yield collate([self.dataset[j] for j in order[i:i + self.batch_size]], self.nmax)
+            yield self._packed.batch(order[i:i + self.batch_size])
 
 
 class DeviceDataset:
@@ -263,6 +346,9 @@ class DevicePrefetcher:
             dev = torch.device("cuda", torch.cuda.current_device())
         self.loader, self.device, self.depth = loader, dev, max(1, depth)
         self.dataset = getattr(loader, "dataset", None)
+        inner = getattr(loader, "loader", loader)      # through train.ShardedLoader
+        if hasattr(inner, "packed"):
+            inner.packed().pin()                       # batches of consecutive graphs become views of pinned memory
 
     def __len__(self):
         return len(self.loader)

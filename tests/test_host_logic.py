@@ -160,3 +160,31 @@ def test_word_drop_keeps_start_and_order():
         assert kept == sorted(kept) and set(kept) <= set(x[:, c].tolist())  # order preserved
     assert not torch.equal(y, x)
     assert torch.equal(word_drop(0, x, 0.0), x)
+
+
+def test_packed_loader_batches_equal_the_per_graph_collate():
+    """DataLoader assembles its batches from the packed dataset (PackedGraphs) with vectorised gathers: every
+    field must equal collate() over the same graphs, for consecutive ids (views), shuffled ids, the ragged
+    tail, a single graph, an empty batch, with and without token ids."""
+    import numpy as np
+    import torch
+
+    from gtg_vae_amd.data import DataLoader, PackedGraphs, collate, synth_graph_list
+
+    for N, B, vocab in ((12, 32, 0), (10, 7, 50)):
+        data = synth_graph_list(3 * B + 5, N, seed=N, vocab=vocab)
+        pk = PackedGraphs(data, N)
+        rng = np.random.default_rng(0)
+        cases = [np.arange(B) + 3, np.arange(len(data) - 5, len(data)), rng.permutation(len(data))[:B], np.array([4]),
+                 np.array([5, 4])]
+        for ids in cases:
+            a, b = pk.batch(ids), collate([data[i] for i in ids], N)
+            for f in ("edge_index", "batch", "adj_padded", "num_nodes", "gold_bits", "dec_seq"):
+                x, y = getattr(a, f), getattr(b, f)
+                assert (x is None and y is None) or (x.dtype == y.dtype and torch.equal(x, y)), (N, f)
+            assert a.gold_edges == b.gold_edges and a.snts == b.snts and a.num_graphs == b.num_graphs
+        assert pk.batch([]).num_graphs == 0
+        for shuffle in (False, True):
+            got = list(DataLoader(data, B, N, shuffle=shuffle, seed=1))
+            assert [g.num_graphs for g in got] == [B, B, B, 5]
+            assert sorted(s for g in got for s in g.snts) == sorted(d.snts for d in data)
