@@ -117,7 +117,7 @@ def mst_cpu_baseline(rows_host, N):
     return res
 
 
-PMC_FILE = "profiles/r02_pmc_traffic.json"
+PMC_FILE = "profiles/r03_pmc_traffic.json"
 PMC_SOURCE_NOTE = ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes over this "
                    "launch shape, committed as %s; NOT measured in this run (null: no pass on record)" % PMC_FILE)
 

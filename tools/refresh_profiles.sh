@@ -1,10 +1,10 @@
 #!/bin/bash
 # On the GPU box: regenerate the bench lines, the rocprofv3 kernel summary and the counter passes kept under
-# profiles/ (copy them from gpurun_out/refresh/ afterwards).  usage: tools/refresh_profiles.sh r02
+# profiles/ (copy them from gpurun_out/refresh/ afterwards).  usage: tools/refresh_profiles.sh r03
 # Each GPU step runs under its own time limit; the script stops at the first failure.  Counter passes run alone
 # (one counter group per run, kernel trace only), the profiled program directly after `--`.
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 repo=$(pwd)
 export TMPDIR=/tmp
 out=$repo/gpurun_out/refresh
@@ -37,4 +37,10 @@ timeout -k 10 200 python3 $repo/tools/lstm_bench.py > $out/${tag}_lstm_bench.txt
 timeout -k 10 200 python3 $repo/tools/planes_bench.py > $out/${tag}_planes_bench.txt 2>> $out/bench.err
 timeout -k 10 200 python3 $repo/tools/proj_ce_bench.py > $out/${tag}_proj_ce_bench.json 2>> $out/bench.err
 timeout -k 10 300 python3 $repo/tools/f16x2_bench.py > $out/${tag}_f16x2_bench.txt 2>> $out/bench.err
+timeout -k 10 200 python3 $repo/tools/text_ops_bench.py > $out/${tag}_text_ops_bench.json 2>> $out/bench.err
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/tprof -- python3 $repo/tools/text_ops_bench.py > $out/tprof.log 2>&1
+cp $out/tprof/*/*_kernel_stats.csv $out/${tag}_text_ops_kernel_stats.csv
+cd $repo
+timeout -k 10 200 python3 $repo/tools/mst_sizes.py > $out/${tag}_mst_sizes.txt 2>> $out/bench.err
+timeout -k 10 300 python3 $repo/tools/pipeline_bench.py > $out/${tag}_pipeline_bench.txt 2>> $out/bench.err
 echo refreshed
