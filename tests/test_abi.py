@@ -44,3 +44,23 @@ def test_bad_arguments_are_reported_not_crashed():
     assert rc == -3 and b"64" in l.gtg_last_error()
     rc = l.gtg_adj_build(None, 0, 2, 0, None, None, None, None, None)
     assert rc == -1
+
+
+def test_host_code_under_address_and_ub_sanitizers():
+    """The library's HOST code built with AddressSanitizer + UndefinedBehaviorSanitizer (make hostcheck) and
+    driven by tests/host/abi_host_check.cpp: every *_workspace_bytes function over a grid of sizes up to the
+    largest accepted, every compute entry point with arguments its validation must refuse before any launch.
+    No GPU involved.  The binary is built by __graft_entry__.build(); it is built here if missing."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "gtg-vae_amd", "csrc")
+    exe = os.path.join(csrc, "san", "abi_host_check")
+    subprocess.run(["make", "-C", csrc, "-j8", "hostcheck"], check=True, capture_output=True, timeout=900)
+    # (verify_asan_link_order=0: the process may run with a preloaded library in front of the sanitizer runtime)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    res = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "host check ok" in res.stdout and "runtime error" not in res.stderr
