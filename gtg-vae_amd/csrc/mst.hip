@@ -115,11 +115,15 @@ __device__ __forceinline__ void stage_row_async(const float* __restrict__ row, f
 // PIN: the row's 64 registers are pinned to v0..v63 for the one-move fetch of the Prim round (see GTG_MST_VISIT).
 // Under that constraint the compiler builds the generic triangular fill with about twice the scalar
 // instructions, which a graph of few nodes (few rounds) does not earn back: the launcher pins from 40 nodes on.
-template <bool TRIU, bool N64, bool PIN>
+// CAP: the most nodes this instantiation takes, 64 or 32.  With 32 the row is 32 registers: half the fill, a quarter
+// of the LDS, and the Prim round fetches its element with one indexed move (no second half, no select).
+template <bool TRIU, bool N64, bool PIN, int CAP = MAXN>
 __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const float* __restrict__ in, int64_t G, int n,
                                                          int32_t* __restrict__ edges, int32_t* __restrict__ count)
 {
-    constexpr int PER_WAVE = TRIU ? (MAXN * (MAXN + 1) / 2) : (MAXN * (MAXN + 1));
+    static_assert(CAP == 32 || CAP == 64, "rows of 32 or 64 registers");
+    static_assert(CAP == 64 || (!N64 && !PIN), "the pinned-register and n = 64 forms are written for 64-register rows");
+    constexpr int PER_WAVE = TRIU ? (CAP * (CAP + 1) / 2) : (CAP * (CAP + 1));
     __shared__ __attribute__((aligned(16))) float lds[WAVES * PER_WAVE];
 
     const int lane = threadIdx.x & 63;
@@ -141,11 +145,11 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
         if (TRIU) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this graph's row has landed
         } else {
-            // full matrices: staged transposed, T[c*(MAXN+1) + r] = mat[r][c]
+            // full matrices: staged transposed, T[c*(CAP+1) + r] = mat[r][c]
             const float* mat = in + g * n * n;
             for (int idx = lane; idx < n * n; idx += 64) {
                 const int r = idx / n, c = idx - r * n;
-                T[c * (MAXN + 1) + r] = mat[idx];
+                T[c * (CAP + 1) + r] = mat[idx];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -185,14 +189,14 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
 #undef GTG_MST_FILL16
         } else {
 #pragma unroll
-            for (int c = 0; c < 64; ++c) {
+            for (int c = 0; c < CAP; ++c) {
                 float v;
                 if (TRIU) {
                     const int cc = c * n - (c * (c - 1)) / 2 - c;
                     const int addr = min(pj4 + 4 * (cc - c), pcj4) + 4 * c;
                     v = *(lds_cptr)(uintptr_t)addr;
                 } else {
-                    v = T[c * (MAXN + 1) + jc];
+                    v = T[c * (CAP + 1) + jc];
                 }
                 if (c < 32)
                     lo[c] = v;
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
         }
         // the triangular form goes through U + U^T - diag(U) in the reference (graph_vae.py:67-69): the diagonal is
         // (d + d) - d, which is d except that +inf gives NaN (vertex absent) and a d above FLT_MAX / 2 gives +inf
-        const float draw = TRIU ? T[jc * n - (jc * (jc - 1)) / 2] : T[jc * (MAXN + 1) + jc];
+        const float draw = TRIU ? T[jc * n - (jc * (jc - 1)) / 2] : T[jc * (CAP + 1) + jc];
         const float diag = TRIU ? (draw + draw) - draw : draw;
         // every LDS read above has returned (waited for just below): the
         // region may be overwritten by the next graph's row now
@@ -250,6 +254,8 @@ __global__ __launch_bounds__(WAVES * 64, TRIU ? 4 : 2) void mst_kernel(const flo
                              "v_mov_b32 %0, v0\n\t"                               \
                              "s_set_gpr_idx_off"                                 \
                              : "=v"(t) : "{v[0:31]}"(lo), "{v[32:63]}"(hi), "s"(mm)); \
+            } else if constexpr (CAP == 32) {                                    \
+                t = lo[mm & 31];                                                 \
             } else {                                                             \
                 float tl = lo[mm & 31], th = hi[mm & 31];                        \
                 asm volatile("" : "+v"(tl), "+v"(th));                           \
@@ -479,6 +485,17 @@ static int mst_launch(bool triu, const float* in, int64_t G, int n, int32_t* edg
         else
             hipLaunchKernelGGL((mst_small_kernel<false>), dim3((unsigned)small_blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
         return check_launch("mst_small_kernel");
+    }
+    if (n <= 32) {
+        // rows of 32 registers, 8.4 KB (triangular) of LDS per block: more blocks fit a CU than the 64-node form's four
+        int64_t b32 = (G + WAVES - 1) / WAVES;
+        const int64_t r32 = (int64_t)num_cus() * (triu ? 8 : 4);
+        if (b32 > r32) b32 = r32;
+        if (triu)
+            hipLaunchKernelGGL((mst_kernel<true, false, false, 32>), dim3((unsigned)b32), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+        else
+            hipLaunchKernelGGL((mst_kernel<false, false, false, 32>), dim3((unsigned)b32), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
+        return check_launch("mst_kernel<32>");
     }
     if (triu && n == 64)
         hipLaunchKernelGGL((mst_kernel<true, true, true>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, in, G, n, edges, count);
