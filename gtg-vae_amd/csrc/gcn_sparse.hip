@@ -278,21 +278,32 @@ __global__ __launch_bounds__(256) void pool_sparse_kernel(const float* __restric
 // its multiply-adds.  A block owns 64 columns of H1c and up to 512 pooled columns c and walks every G-th
 // graph: it stages the graph's rows of the slab in LDS, aggregates them sparsely (lane k holds A_b[i, k],
 // ballot, v_readlane coefficient, one LDS read per nonzero), then every lane -- one pooled column c each --
-// adds g * Y[am, 0..63] to its 64 accumulators (LDS row stride 65: lanes on different rows read different
-// banks, lanes on the same row share a broadcast).  Two graphs are in flight in registers (rows, adjacency
-// rows, g and am): the loads of graph t + 2 are issued before graph t is accumulated.  The columns won by a prototype row
-// arrive as n more items: row i of the prototype block of dT2c (the sum of g over the graphs whose maximum
-// row i won) times prototype row i of H1c.  Each group of graphs leaves a partial dW2, stored transposed (c along
-// the lanes: whole 256-byte runs); dw_reduce_pair_kernel adds the groups in order and transposes back: reproducible.
+// adds g * Y[am, 0..63] to its 64 accumulators, two columns per 8-byte LDS read (row stride 66: lanes on
+// different rows read different bank pairs unless the rows are 32 apart, lanes on the same row share a broadcast;
+// 8-byte reads move twice the bytes per LDS cycle of 4-byte ones).  The items form a pipeline with ONE barrier
+// each: phase t aggregates item t + 1, accumulates item t and stages item t + 2 (two staged and two aggregated
+// tiles), and the three kinds of operand -- slab rows, adjacency rows, per-column gradient and winning row --
+// are fetched two to three phases ahead of their use.  The columns won by a prototype row arrive as n more items:
+// row i of the prototype block of dT2c (the sum of g over the graphs whose maximum row i won) times prototype
+// row i of H1c.  Each group of graphs leaves a partial dW2, stored transposed (c along the lanes: whole 256-byte
+// runs); dw_reduce_pair_kernel adds the groups in order and transposes back: reproducible.
+// What bounds it is instruction issue, the scalar unit first (ablations: the parts' times add up; more
+// instructions per nonzero for more reads in flight -- eight rows side by side, two nonzeros per trip, straight-line
+// blocks of four -- all measured slower): every load is one buffer instruction (scalar row offset, item-independent
+// lane offset, the range check of the resource instead of index clamps per load), rows are staged unconditionally,
+// the walk's bit clear is one s_bitset0_b64.  70.8 -> 55.5 us at B = 512, n = 64, d = 512 (8-byte reads -8.5, the
+// one-barrier pipeline -1, the leaner instruction stream -6), bit-identical results.
 constexpr int DW_THREADS = 512;
 constexpr int DW_COLS = 64;
-constexpr int DW_LD = 65;
+constexpr int DW_LD = 66;   // row stride of the LDS tiles in floats: even, so that a lane reads two columns with one 8-byte load;
+                             // such loads go over 64 banks, and 66 = 2 (mod 64) puts rows i and i + 32 only on the same pair
 constexpr int DW_CPB = 512;   // pooled columns per block: 64 per wave
-// 32 groups x 16 slabs at 2d = 1024: 512 blocks, two per CU (hence the bound of 4 waves per SIMD, 128 registers):
-// a block spends much of an item waiting (barriers, the dependent LDS reads of the adjacency walk) and the second
-// block fills those waits -- worth more than the second copy of the partials costs (16 groups, one block per
-// CU: 93 + 8 us; 32 groups: 13 us less per step).
+// 32 groups x 16 slabs at 2d = 1024: 512 blocks, two per CU (hence the bound of 4 waves per SIMD, 128 registers;
+// 4 x 16.5 KB of LDS per block): a block spends much of an item waiting (the barrier, the dependent LDS reads of the
+// adjacency walk) and the second block fills those waits -- worth more than the second copy of the partials costs
+// (16 groups, one block per CU: 93 + 8 us; 32 groups: 13 us less per step).
 constexpr int DW_GROUPS = 32;
+constexpr int DW_INFLIGHT = 2;  // batches of four 8-byte LDS reads in flight while a lane accumulates (2 or 3)
 
 __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* __restrict__ adj, const float* __restrict__ h1c,
                                                                 int ldh, const float* __restrict__ dpool,
@@ -302,12 +313,19 @@ __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* 
                                                                 const float* __restrict__ proto_rows, int B, int n, int d,
                                                                 float* __restrict__ partial)
 {
-    __shared__ float Hs[64 * DW_LD];
-    __shared__ float Y[2][64 * DW_LD];  // alternate between items: one is accumulated from while the next is built
+    // Four tiles: the staged rows and the aggregated rows of two items each, so that one barrier per item suffices
+    // (phase t aggregates item t + 1, accumulates item t and stages item t + 2).  4 x 16.5 KB: two blocks per CU.
+    __shared__ float Hs[2][64 * DW_LD];
+    __shared__ __align__(16) float Y[2][64 * DW_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in a scalar register: row indices stay scalar
-    const float* const hcol = h1c + blockIdx.x * DW_COLS + lane;  // this lane's column of H1c while staging
-    const int G = gridDim.y, gr = blockIdx.y;
+    // Blocks go to the eight XCDs in turn (linear id mod 8), and each XCD has its own L2: the blocks of one group
+    // of graphs -- one per 64-column slab -- are dealt to ONE XCD, so that the group's adjacency rows, gradients and
+    // winning rows are fetched into that L2 once instead of once per slab, and a row's 256-byte pieces are asked
+    // for together.  (DW_GROUPS is a multiple of 8.)
+    const int nslab = ldh / DW_COLS;
+    const int slab = (blockIdx.x >> 3) % nslab;
+    const int G = DW_GROUPS, gr = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / nslab);
     const int c = blockIdx.z * DW_CPB + tid;      // this lane's pooled column while accumulating
     const bool c_ok = c < d;
     const int cc = min(c, d - 1);
@@ -318,7 +336,8 @@ __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* 
     const int items = ng + np;
 
     for (int i = tid; i < 64 * DW_LD; i += DW_THREADS) {
-        Hs[i] = 0.f;  // rows past a graph's extent are read with a zero coefficient: keep them finite
+        Hs[0][i] = 0.f;  // rows past a graph's extent are read with a zero coefficient: keep them finite
+        Hs[1][i] = 0.f;
         Y[0][i] = 0.f;
         Y[1][i] = 0.f;
     }
@@ -326,17 +345,11 @@ __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* 
 #pragma unroll
     for (int k = 0; k < DW_COLS; ++k) acc[k] = 0.f;
 
-    // Two items are in flight in registers: the loads of item t + 2 are issued while item t is accumulated
-    // and have the whole of item t + 1 to land.
-    struct Item {
-        float row[8], a[8], g;
-        int am, nb;  // nb < 0: a prototype row
-    };
     // Per item (this block's graphs, then its prototype rows), item t in lane t: extent (-1 marks a prototype
-    // row), first stored row, and the row of the (B x d) arrays that holds its g.  A fetch then starts its loads
-    // at once, and it is the same straight-line code for both kinds of item: with a branch around the loads the
-    // compiler drains every outstanding load at the top of the loop, which undoes the prefetch.  (At most 64
-    // items per group: checked on the host.)
+    // row) and first stored row.  Every load below is straight-line code at clamped indices, the same for both
+    // kinds of item and for items past the end (a harmless repeat of the last one): with a branch around the
+    // loads the compiler drains every outstanding load at the top of the loop, which undoes the prefetch.  (At
+    // most 64 items per group: checked on the host.)
     int nbv = -1, offv = 0;
     if (lane < ng) {
         nbv = meta[gr + G * lane];
@@ -344,82 +357,170 @@ __global__ __launch_bounds__(DW_THREADS, 4) void dw2_sparse_kernel(const float* 
     } else if (lane < items) {
         offv = R + gr + G * (lane - ng);
     }
-    auto fetch = [&](Item& p, int it_raw) {
-        const int it = min(it_raw, items - 1);  // past the end: a harmless repeat of the last item
+    // The three kinds of operand of an item are fetched a different number of phases ahead of their use, each
+    // into one register set: its rows of the H1c slab (staged two phases before the item is accumulated), its
+    // adjacency rows (walked one phase before) and its head -- per pooled column the gradient and the winning row.
+    struct Head {
+        float g;
+        int am, nb;  // nb < 0: a prototype row
+    };
+    // A load is one buffer instruction: a resource that starts at the item's first row (adjacency block), a scalar
+    // offset for row wave + 8 t -- clamped to n - 1: past the item's extent that is a row of the next graph or a
+    // prototype row (the stored rows end with n prototype rows), loaded and never used -- and a per-lane offset
+    // that depends on neither.
+    float row[8], a[8];
+    int srow[8], sadj[8];  // scalars (the wave index is in a scalar register)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int j = min(wave + 8 * t, n - 1);
+        srow[t] = 4 * j * ldh;
+        sadj[t] = 4 * j * n;
+    }
+    const int lane_r = 4 * (slab * DW_COLS + lane), lane_a = 4 * min(lane, n - 1);
+    auto load_rows = [&](int it_raw) {
+        const int it = min(it_raw, items - 1);
+        const int nb = __builtin_amdgcn_readlane(nbv, it), off = __builtin_amdgcn_readlane(offv, it);
+        // a prototype row is fetched with the whole prototype block (rows R .. R + n - 1)
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h1c) + (long long)(nb < 0 ? R : off) * ldh, 0,
+                                                          4 * n * ldh, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) row[t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane_r, srow[t], 0));
+    };
+    auto load_adj = [&](int it_raw) {
+        const int it = min(it_raw, items - 1);
+        const int nb = __builtin_amdgcn_readlane(nbv, it);
+        const int b = nb < 0 ? 0 : gr + G * it;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(adj) + (long long)b * n * n, 0, 4 * n * n, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[t] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane_a, sadj[t], 0));
+    };
+    auto load_head = [&](Head& h, int it_raw) {
+        const int it = min(it_raw, items - 1);
         const int nb = __builtin_amdgcn_readlane(nbv, it), off = __builtin_amdgcn_readlane(offv, it);
         const bool proto = nb < 0;
         const int b = proto ? 0 : gr + G * it;
-        const int k_last = max(nb - 1, 0);
-        const float* A = adj + (long long)b * n * n + min(lane, n - 1);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int j = wave + 8 * t;
-            p.row[t] = hcol[(off + min(j, k_last)) * ldh];  // scalar row offset, 32 bits (checked on the host)
-            p.a[t] = keep_if(A[min(j, n - 1) * n], j < nb && lane < nb);
-        }
         const int am = argmax[(long long)b * d + cc];
         // a prototype row's gradient: row off of dT2c, or row off - R of a separate (n, d) block
         const float* gsrc = proto ? (proto_rows ? proto_rows + (long long)(off - R) * d : dT2c + (long long)off * d)
                                   : dpool + (long long)b * d;
         const bool real = proto || (am >= 0 && am < nb);
-        p.g = keep_if(gsrc[cc], c_ok && real);
-        p.am = proto ? off - R : (real ? am : 0);
-        p.nb = nb;
+        h.g = keep_if(gsrc[cc], c_ok && real);
+        h.am = proto ? off - R : (real ? am : 0);
+        h.nb = nb;
     };
-    auto process = [&](Item& p, int it) {
-        const int nb = p.nb;
-        const bool proto = nb < 0;  // block-uniform
-        float* const Yc = Y[it & 1];
-        if (!proto) {
+    // rows of the item in `row` -> Hb, all 64 of them (rows past the extent are never read; for a prototype row
+    // the whole prototype block is staged and aggregate() picks the row)
+    auto stage = [&](float* Hb) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int j = wave + 8 * t;
-                if (j < nb) Hs[j * DW_LD + lane] = p.row[t];
-            }
-        } else if (wave == 0) {
-            Yc[p.am * DW_LD + lane] = p.row[0];
+        for (int t = 0; t < 8; ++t) Hb[(wave + 8 * t) * DW_LD + lane] = row[t];
+    };
+    // Yc[i, :] = sum_k A[i, k] Hb[k, :] for the wave's rows i = wave, wave + 8, ...: the nonzeros of a row in ascending k
+    auto aggregate = [&](const Head& h, const float* Hb, float* Yc) {
+        const int nb = h.nb;
+        if (nb < 0) {  // block-uniform
+            if (wave == 0) Yc[h.am * DW_LD + lane] = Hb[h.am * DW_LD + lane];
+            return;
         }
-        __syncthreads();
-        if (!proto) {
+        const unsigned long long cols = nb >= 64 ? ~0ull : (1ull << nb) - 1ull;  // columns of the graph's own nodes
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int i = wave + 8 * t;
-                if (i >= nb) break;  // wave-uniform
-                unsigned long long mask = __ballot(p.a[t] != 0.f);
-                float y = 0.f;
-                while (mask) {
-                    const int k = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.a[t]), k));
-                    y = fmaf(ak, Hs[k * DW_LD + lane], y);
-                }
-                Yc[i * DW_LD + lane] = y;
+        for (int t = 0; t < 8; ++t) {
+            const int i = wave + 8 * t;
+            if (i >= nb) break;  // wave-uniform
+            unsigned long long mask = __ballot(a[t] != 0.f) & cols;
+            float y = 0.f;
+            while (mask) {
+                const int k = __ffsll((long long)mask) - 1;
+                asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(k));  // (the compiler takes three instructions for mask &= mask - 1)
+                const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[t]), k));
+                y = fmaf(ak, Hb[k * DW_LD + lane], y);
             }
+            Yc[i * DW_LD + lane] = y;
         }
-        __syncthreads();  // Y complete; Hs free for the next item
-        const float g = p.g;
-        const float* yrow = Yc + p.am * DW_LD;
+    };
+    auto accumulate = [&](const Head& h, const float* Yc) {
+        const float g = h.g;
         if (wave_live) {
-#pragma unroll
-            for (int k = 0; k < DW_COLS; ++k) acc[k] = fmaf(g, yrow[k], acc[k]);
+            // The 32 reads are written out as single ds_read_b64 (left to itself the compiler pairs them into
+            // ds_read2_b64, which goes over 32 banks at half the rate), in eight batches of four with DW_INFLIGHT
+            // batches in flight; a wait carries the batch it retires as operands, so that no use can move above it.
+            const unsigned ya = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Yc + 4u * (unsigned)(h.am * DW_LD);
+            f32x2 v[DW_INFLIGHT * 4];
+#define DW_READ4(base, kb)                                                                                             \
+    asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%5+8\n\tds_read_b64 %2, %4 offset:%5+16\n\t"  \
+                 "ds_read_b64 %3, %4 offset:%5+24"                                                                     \
+                 : "=&v"(v[base]), "=&v"(v[base + 1]), "=&v"(v[base + 2]), "=&v"(v[base + 3])                           \
+                 : "v"(ya), "n"(32 * (kb)))
+#define DW_WAIT4(cnt, base)                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(%4)"                                                                               \
+                 : "+v"(v[base]), "+v"(v[base + 1]), "+v"(v[base + 2]), "+v"(v[base + 3])                               \
+                 : "n"(cnt))
+#define DW_FMA4(base, kb)                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
+        acc[8 * (kb) + 2 * q] = fmaf(g, v[base + q][0], acc[8 * (kb) + 2 * q]);                                        \
+        acc[8 * (kb) + 2 * q + 1] = fmaf(g, v[base + q][1], acc[8 * (kb) + 2 * q + 1]);                                \
+    }
+            // batch kb (columns 8 kb .. 8 kb + 7) lives in slot kb % DW_INFLIGHT
+#define DW_STEP(kb)                                                                                                    \
+    DW_WAIT4((DW_INFLIGHT - 1) * 4 < (7 - (kb)) * 4 ? (DW_INFLIGHT - 1) * 4 : (7 - (kb)) * 4, 4 * ((kb) % DW_INFLIGHT)); \
+    DW_FMA4(4 * ((kb) % DW_INFLIGHT), kb);                                                                             \
+    if ((kb) + DW_INFLIGHT < 8) DW_READ4(4 * ((kb) % DW_INFLIGHT), (kb) + DW_INFLIGHT < 8 ? (kb) + DW_INFLIGHT : 0)
+            DW_READ4(0, 0);
+            DW_READ4(4, 1);
+            if (DW_INFLIGHT > 2) DW_READ4(4 * (2 % DW_INFLIGHT), 2);
+            DW_STEP(0);
+            DW_STEP(1);
+            DW_STEP(2);
+            DW_STEP(3);
+            DW_STEP(4);
+            DW_STEP(5);
+            DW_STEP(6);
+            DW_STEP(7);
+#undef DW_STEP
+#undef DW_READ4
+#undef DW_WAIT4
+#undef DW_FMA4
         }
-        // (after the accumulation, not before it: the item's sixteen row / adjacency registers are then free
-        // while the 64 LDS reads above run, so several of them can be in flight instead of one at a time)
-        fetch(p, it + 2);
     };
-    Item p0, p1;
+    // phase `it`: hc = head of item it, hn = head of item it + 1
+    auto phase = [&](Head& hc, const Head& hn, int it) {
+        if (it + 1 < items) aggregate(hn, Hs[(it + 1) & 1], Y[(it + 1) & 1]);
+        load_adj(it + 2);            // a[] is free again; walked one phase from now
+        accumulate(hc, Y[it & 1]);
+        load_head(hc, it + 2);       // accumulated two phases from now
+        if (it + 2 < items) stage(Hs[it & 1]);   // Hs[it & 1] was last read one phase ago
+        load_rows(it + 3);
+        __syncthreads();
+    };
+    Head h0, h1;
+    h0.g = h1.g = 0.f;
+    h0.am = h1.am = 0;
+    h0.nb = h1.nb = 0;
     if (items > 0) {
-        fetch(p0, 0);
-        fetch(p1, 1);
+        load_rows(0);
+        load_adj(0);
+        load_head(h0, 0);
+        load_head(h1, 1);
     }
     __syncthreads();  // LDS cleared
+    if (items > 0) {
+        stage(Hs[0]);
+        load_rows(1);
+    }
+    __syncthreads();
+    if (items > 0) {
+        aggregate(h0, Hs[0], Y[0]);
+        load_adj(1);
+        if (items > 1) stage(Hs[1]);
+        load_rows(2);
+    }
+    __syncthreads();
     for (int it = 0; it < items; it += 2) {
-        process(p0, it);
-        if (it + 1 < items) process(p1, it + 1);
+        phase(h0, h1, it);
+        if (it + 1 < items) phase(h1, h0, it + 1);
     }
     // partial[group][column of H1c][c]: c runs along the lanes, so every store instruction is one 256-byte run
     if (c_ok) {
-        float* dst = partial + ((long long)gr * ldh + blockIdx.x * DW_COLS) * d + c;
+        float* dst = partial + ((long long)gr * ldh + slab * DW_COLS) * d + c;
 #pragma unroll
         for (int k = 0; k < DW_COLS; ++k) dst[(long long)k * d] = acc[k];
     }
@@ -690,7 +791,7 @@ int dw2_sparse(const float* adj, const float* h1c, int H, const float* dpool, co
     if ((reinterpret_cast<uintptr_t>(partial) & 15) != 0 || (reinterpret_cast<uintptr_t>(dW2) & 15) != 0)
         return set_error(GTG_ERR_INVALID, "dw2_sparse: outputs must be 16-byte aligned");
     ProfScope prof(s, "dw2_sparse", B * n, H, d);
-    hipLaunchKernelGGL(dw2_sparse_kernel, dim3(H / DW_COLS, DW_GROUPS, (d + DW_CPB - 1) / DW_CPB), dim3(DW_THREADS), 0, s,
+    hipLaunchKernelGGL(dw2_sparse_kernel, dim3(H / DW_COLS * DW_GROUPS, 1, (d + DW_CPB - 1) / DW_CPB), dim3(DW_THREADS), 0, s,
                        adj, h1c, H, dpool, argmax, meta, dT2c, proto_rows, (int)B, n, d, partial);
     if (int rc = check_launch("dw2_sparse_kernel")) return rc;
     if (defer_reduce) return GTG_OK;
