@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch one GEMM shape a few times (for rocprofv3 --pmc passes).
-usage: gemm_one.py {nt|nn|nnmask|tn|rows_nnmask|rows_nt|rows_planes} [reps]
+usage: gemm_one.py {nt|nn|nnmask|tn|rows_nnmask|rows_nt|rows_planes} [reps]  |  gemm_one.py shape M N K {nt|nn|tn} [reps]
 The rows_* shapes are the compact-row encoder GEMMs: 32832 allocated rows of which the
 device-side count (20759, the mean of the benchmark's batches) are computed; rows_planes is
 rows_nnmask with both operands arriving as three bf16 planes (the training step's form)."""
@@ -15,6 +15,18 @@ MODE = os.environ.get("GTG_MATRIX_MODE", "f32")  # matrix pipe under test: f32 |
 from gtg_vae_amd import functional as Fn
 
 which = sys.argv[1] if len(sys.argv) > 1 else "nt"
+if which == "shape":   # gemm_one.py shape M N K {nt|nn|tn} [reps]
+    M_, N_, K_, lay = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    reps = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+    torch.manual_seed(0)
+    akc, bkc = lay != "tn", lay == "nt"
+    A = torch.randn((M_, K_) if akc else (K_, M_), device="cuda")
+    B = torch.randn((N_, K_) if bkc else (K_, N_), device="cuda")
+    for _ in range(reps):
+        out = Fn.gemm(A, B, akc, bkc, matrix_mode=MODE)
+    torch.cuda.synchronize()
+    print("done", which, out.shape)
+    sys.exit(0)
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 BN, H, D = 32768, 1024, 512
 torch.manual_seed(0)
