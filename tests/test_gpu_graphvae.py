@@ -151,7 +151,7 @@ def test_compact_encoder_edge_cases(N, d):
     assert _relerr(outs[0][0], outs[1][0]) < 1e-6
 
 
-@pytest.mark.parametrize("B,N,d", [(130, 64, 512), (300, 10, 256), (256, 33, 288), (600, 10, 512)])
+@pytest.mark.parametrize("B,N,d", [(130, 64, 512), (300, 10, 256), (256, 33, 288), (600, 10, 512), (96, 64, 768)])
 def test_conv2_weight_gradient_through_the_pool_routing(B, N, d):
     """At B*d >= 65536 the compact backward takes dW2 from the pooled gradient and the winning rows
     (one aggregated row of H1 per graph and column) instead of the dense product: awkward graphs
@@ -160,7 +160,9 @@ def test_conv2_weight_gradient_through_the_pool_routing(B, N, d):
     wave of pooled columns is partly idle (288); all four gradients against the oracle.  At these
     sizes (2048 stored rows or more, hidden width a multiple of 64) conv1's weight gradient is
     taken through the nonzeros of the adjacency rows as well: n = 64, 10 and 33 columns, one column
-    per lane (2d = 512, 576) and two (2d = 1024, with n = 64 and with n = 10)."""
+    per lane (2d = 512, 576) and two (2d = 1024, with n = 64 and with n = 10).  d = 768: more pooled columns
+    than one block of the routing kernel takes (512), the second block's last waves idle, and the complete
+    graphs there have all 64 nodes (every adjacency entry nonzero, all 64 columns walked)."""
     from gtg_vae_amd import functional as Fn
     from oracle import graphvae_oracle as O
 
@@ -179,7 +181,7 @@ def test_conv2_weight_gradient_through_the_pool_routing(B, N, d):
         elif kind == 5:
             edges += [(o, o + 4)] * 3 + [(o + 4, o)]
         elif kind == 6:
-            m = min(N, 9)
+            m = N if d > 512 else min(N, 9)
             edges += [(o + i, o + j) for i in range(m) for j in range(m) if i != j]
         elif kind == 7:
             m = int(rng.integers(2, N + 1))
