@@ -10,11 +10,13 @@ are resident in HBM before the timed region.  Workload = BASELINE.json
 configs[2]: N=64 nodes, batch 512 PER GPU (weak scaling), d=512, mlp_hid=512,
 fp32.  For N>1 launch with torch.distributed.run (one rank per GPU, RCCL).
 
-The timed region replays the step as HIP graphs (--eager: plain launches).
+On one GPU the timed region replays the step as one HIP graph (--eager: plain
+launches); with more GPUs the step is launched eagerly around its two gradient
+all-reduces (--graph-segments: three graphs with the collectives between them).
 Prints ONE JSON line (rank 0) with the headline metric, the roofline of the
 dominant kernel (fp32 MFMA GEMM; executed FLOPs over its HIP-event time, taken
-in the timed region with --eager, else over --profile-steps eager steps that
-continue the same loop right after it) and, at N=1, the CPU baseline (the
+over --profile-steps eager steps that continue the same loop right after the
+timed region, which itself carries no events) and, at N=1, the CPU baseline (the
 build-owned PyTorch-CPU oracle of the same step, timed on this host's cores)
 plus the batched-MST read-out figure.
 """
@@ -257,6 +259,8 @@ def main():
                          "default); plain bf16 operands (loss tolerance 1e-3)")
     ap.add_argument("--no-alt", action="store_true", help="skip the short extra runs in the other matrix modes")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying HIP graphs")
+    ap.add_argument("--graph-segments", action="store_true",
+                    help="with more than one GPU: replay the launches between the all-reduces as HIP graphs (default there: eager)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager steps after the timed region, for per-kernel HIP-event times")
     args = ap.parse_args()
     if os.environ.get("GTG_HANG_DUMP"):  # debugging aid: dump all Python stacks if the run stalls
@@ -290,7 +294,12 @@ def main():
     gen = torch.Generator().manual_seed(4321 + rank)
     eps = [torch.randn(B, d, generator=gen).to(dev) for _ in range(nb)]
     tr.set_kl_weight(0.5)
-    use_graph = not args.eager
+    # One GPU: the step is replayed as a single HIP graph.  More than one: the launches between the two gradient
+    # all-reduces could be replayed as three graphs, but with a live RCCL group the eagerly launched step is the
+    # faster of the two (tools/rccl_graph_probe.py: 0.604 against 0.622 ms) -- the host runs far enough ahead of the
+    # GPU for the launches to cost nothing, and a collective between two graph launches costs more than between
+    # two kernels.  --graph-segments replays the segments as graphs all the same.
+    use_graph = not args.eager and (world == 1 or args.graph_segments)
 
     def one_step(i, graph=use_graph):
         tr.load_batch(batches[i % nb], eps[i % nb])
@@ -313,8 +322,6 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
-    if not use_graph:
-        _lib.profile_enable(True)
 
     def timed_region(first):
         """EXACTLY args.steps steps between two (barrier + device synchronize) brackets; the slowest rank's time."""
@@ -342,22 +349,17 @@ def main():
     regions = [timed_region(args.warmup + r * args.steps) for r in range(repeats)]
     elapsed = sorted(regions)[len(regions) // 2]
     steps_done = args.warmup + repeats * args.steps
-    prof_steps = args.steps * repeats
-    if not use_graph:
-        used = [(args.warmup + i) % nb for i in range(prof_steps)]
-        eff_rows = sum(census[j]["rows"] for j in used) / len(used)
-        eff_sq = sum(census[j]["sq"] for j in used) / len(used)
-    if use_graph:
-        # a replayed graph has no per-launch events: the same steps are continued eagerly, outside the timed
-        # region, with HIP events around every GEMM launch (same kernels, same shapes, same batches)
-        prof_steps = max(1, args.profile_steps)
-        _lib.profile_enable(True)
-        used = [(steps_done + i) % nb for i in range(prof_steps)]
-        eff_rows = sum(census[j]["rows"] for j in used) / len(used)
-        eff_sq = sum(census[j]["sq"] for j in used) / len(used)
-        for i in range(prof_steps):
-            one_step(steps_done + i, graph=False)
-        torch.cuda.synchronize()
+    # The timed region carries no events (a replayed graph has no per-launch events anyway): the same steps are
+    # continued eagerly, outside it, with HIP events around every GEMM launch (same kernels, shapes and batches;
+    # every rank runs them, so that the collectives still match).
+    prof_steps = max(1, args.profile_steps)
+    _lib.profile_enable(True)
+    used = [(steps_done + i) % nb for i in range(prof_steps)]
+    eff_rows = sum(census[j]["rows"] for j in used) / len(used)
+    eff_sq = sum(census[j]["sq"] for j in used) / len(used)
+    for i in range(prof_steps):
+        one_step(steps_done + i, graph=False)
+    torch.cuda.synchronize()
     prof = _lib.profile_report()
     _lib.profile_enable(False)
     # kernel launches of one step (the library counts its launches on the host)
@@ -411,9 +413,8 @@ def main():
                     "fp32_equivalent_frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                     "launch": {"M": m_, "N": n_, "K": k_, "flops": fl, "avg_ms": avg_ms, "launches": cnt,
                                "stored_rows": eff_rows if ":" in name else None,
-                               "timed_with": "HIP events on the launch stream, %s" % (
-                                   "over the timed steps" if not use_graph else
-                                   "%d eager steps right after the timed graph replays" % prof_steps)}}
+                               "timed_with": "HIP events on the launch stream, %d eager steps right after the timed %s" % (
+                                   prof_steps, "graph replays" if use_graph else "steps")}}
             for r in sorted(big, key=lambda r: -r[5])[:8]:
                 kern["%s M%d N%d K%d" % r[:4]] = {"avg_ms": r[5] / r[4], "tflops": executed_flops(r) / (r[5] / r[4] * 1e-3) / 1e12}
         # FLOPs the step's GEMM launches executed (the sparse row-product kernels of the encoder, which replace

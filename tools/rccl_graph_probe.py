@@ -24,17 +24,18 @@ tr.buckets.world = 2
 batches = [synth_graph_batch(B, N, seed=1234 + i).to("cuda") for i in range(2)]
 eps = [torch.randn(B, d).cuda() for _ in range(2)]
 tr.set_kl_weight(0.5)
-for mode in (False, True):
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+for mode in (False, True) * reps:
     for i in range(10):
         tr.load_batch(batches[i % 2], eps[i % 2])
         tr.run_loaded(update=True, use_graph=mode)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(50):
+    for i in range(200):
         tr.load_batch(batches[i % 2], eps[i % 2])
         tr.run_loaded(update=True, use_graph=mode)
     torch.cuda.synchronize()
-    print("use_graph=%s: %.3f ms/step, recon %.5f kl %.5f" % (mode, (time.perf_counter() - t0) / 50 * 1e3,
+    print("use_graph=%s: %.3f ms/step, recon %.5f kl %.5f" % (mode, (time.perf_counter() - t0) / 200 * 1e3,
                                                              tr.scalars[0].item(), tr.scalars[1].item()), flush=True)
 dist.barrier()
 dist.destroy_process_group()
