@@ -53,6 +53,9 @@ _SIGS = {
     "gtg_bce_loss_bwd": (c_int, [_P, _P, c_float, _P, c_int64, c_int, c_int, _P, _P]),
     "gtg_decoder_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "gtg_decoder_bwd": (c_int, [_P] * 7 + [c_int, c_float, _P, c_int64, c_int, c_int, c_int] + [_P] * 5 + [_P, c_size_t, _P]),
+    "gtg_head_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "gtg_head_fwd_bwd": (c_int, [_P] * 11 + [c_int64, c_int, c_int, c_int] + [_P] * 20 + [_P, c_float, c_float, c_float]
+                         + [_P, c_size_t, _P]),
     "gtg_stage_batch": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P]),
     "gtg_gather_batch": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, _P, c_int64, _P, _P, c_int64, _P, _P, _P]),
     "gtg_proj_ce_fwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
@@ -71,6 +74,7 @@ _SIGS = {
                                       c_int, _P, c_size_t, _P]),
     "gtg_dropout": (c_int, [_P, c_int64, c_float, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     "gtg_adam_step": (c_int, [_P] * 4 + [c_int64, _P, c_float, c_float, c_float, c_float, c_float, _P]),
+    "gtg_adam_update": (c_int, [_P] * 4 + [c_int64, _P, c_float, c_float, c_float, c_float, _P]),
     "gtg_gemm_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, c_int, _P, c_int, _P, c_size_t, c_int, _P]),
     "gtg_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gtg_gemm_rows_workspace_bytes": (c_size_t, []),

@@ -672,21 +672,12 @@ int gtg_latent_fwd(const float* h, const float* Wmu, const float* bmu, const flo
     return reparam_kl(mu, logvar, eps, B, d, z, partial, kl, s);
 }
 
-int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const float* mu, const float* logvar,
-                   const float* eps, const float* dz, float kl_w, const float* kl_w_dev, int64_t num_graphs, int d,
-                   float* dWmu, float* dbmu, float* dWlv, float* dblv, float* dh, void* ws, size_t ws_bytes,
-                   void* stream)
+// The latent head's backward; dboth: 2 B d floats, cs: colsum_workspace(B, d), slabs: gemm_splitk_workspace(d, d, B, 1).
+static int latent_bwd_launches(const float* h, const float* Wmu, const float* Wlv, const float* mu, const float* logvar,
+                               const float* eps, const float* dz, float kl_w, const float* kl_w_dev, int B, int d,
+                               float* dWmu, float* dbmu, float* dWlv, float* dblv, float* dh, float* dboth, float* cs,
+                               float* slabs, hipStream_t s)
 {
-    GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
-    GTG_REQUIRE(h && Wmu && Wlv && mu && logvar && eps && dWmu && dbmu && dWlv && dblv && dh, "null pointer");
-    hipStream_t s = (hipStream_t)stream;
-    const int B = (int)num_graphs;
-    Carver c(ws, ws_bytes);
-    c.take<float>((size_t)((num_graphs * d + 255) / 256) + 1);
-    float* dboth = c.take<float>((size_t)2 * B * d);
-    float* cs = reinterpret_cast<float*>(c.take<char>(colsum_workspace(B, d)));
-    float* slabs = reinterpret_cast<float*>(c.take<char>(gemm_splitk_workspace(d, d, B, 1)));
-    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_latent_bwd: workspace too small");
     // When the two weight matrices lie back to back in memory, [Wmu; Wlv] is one (2d, d) operand: dmu and dlogvar
     // are then kept as the halves of (B, 2d) rows and dh = [dmu | dlogvar] [Wmu; Wlv] is a single GEMM.
     const bool stacked = (Wlv == Wmu + (size_t)d * d);
@@ -712,15 +703,43 @@ int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const flo
         GTG_TRY(gemm(g, s));
         GTG_TRY(gemm(gh, s));
     } else {
-        // both weight gradients as a batch of two, and dh beside them: one launch
+        // both weight gradients as a batch of two, and dh beside them: one launch, in whose first blocks the two
+        // bias gradients (column sums of dmu and dlogvar, which this launch only reads) ride as side jobs
         g.batch = 2; g.strideA = dlv - dmu; g.strideB = 0; g.strideC = dWlv - dWmu;
+        SideJobs side;
+        const bool riding = side.add_colsum(dmu, B, d, ld, dbmu) && side.add_colsum(dlv, B, d, ld, dblv);
+        if (riding) g.side = &side;
         GTG_TRY(gemm_pair(g, gh, s));
+        if (!stacked) {
+            gh.A = dlv; gh.B = Wlv; gh.epi = EPI_ACCUM;
+            GTG_TRY(gemm(gh, s));
+        }
+        if (riding) return GTG_OK;
+        return colsum_pair(dmu, B, d, ld, dbmu, dlv, B, d, ld, dblv, cs, s);
     }
     if (!stacked) {
         gh.A = dlv; gh.B = Wlv; gh.epi = EPI_ACCUM;
         GTG_TRY(gemm(gh, s));
     }
     return colsum_pair(dmu, B, d, ld, dbmu, dlv, B, d, ld, dblv, cs, s);
+}
+
+int gtg_latent_bwd(const float* h, const float* Wmu, const float* Wlv, const float* mu, const float* logvar,
+                   const float* eps, const float* dz, float kl_w, const float* kl_w_dev, int64_t num_graphs, int d,
+                   float* dWmu, float* dbmu, float* dWlv, float* dblv, float* dh, void* ws, size_t ws_bytes,
+                   void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && d >= 1, "bad size");
+    GTG_REQUIRE(h && Wmu && Wlv && mu && logvar && eps && dWmu && dbmu && dWlv && dblv && dh, "null pointer");
+    const int B = (int)num_graphs;
+    Carver c(ws, ws_bytes);
+    c.take<float>((size_t)((num_graphs * d + 255) / 256) + 1);
+    float* dboth = c.take<float>((size_t)2 * B * d);
+    float* cs = reinterpret_cast<float*>(c.take<char>(colsum_workspace(B, d)));
+    float* slabs = reinterpret_cast<float*>(c.take<char>(gemm_splitk_workspace(d, d, B, 1)));
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_latent_bwd: workspace too small");
+    return latent_bwd_launches(h, Wmu, Wlv, mu, logvar, eps, dz, kl_w, kl_w_dev, B, d, dWmu, dbmu, dWlv, dblv, dh, dboth,
+                               cs, slabs, (hipStream_t)stream);
 }
 
 // Stand-alone reparameterisation + KL (GTVAE.reparameterize / GTVAE.loss_kl as
@@ -823,6 +842,10 @@ size_t gtg_decoder_bwd_workspace_bytes(int64_t num_graphs, int d, int hid, int m
     return c.off;
 }
 
+static int decoder_bwd_launches(const float* z, const float* D1, const float* D2, const float* y1, const float* dy2, int B,
+                                int d, int hid, int m_out, float* dD1, float* dc1, float* dD2, float* dc2, float* dz,
+                                const DecBwdWs& w, const SideJobs* extra, hipStream_t s);
+
 // Exactly one of (dout) and (adj_target) is given:
 //   dout        gradient w.r.t. the decoder's sigmoid output (generic autograd path)
 //   adj_target  fuse the BCE backward: dy2 is produced straight from out/targets
@@ -850,14 +873,32 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
         GTG_TRY(sigmoid_bwd(out, dout, (int64_t)B * m_out, w.dy2, s));
     else
         dy2 = dout;  // already the gradient w.r.t. the logits (gtg_bce_loss_fwd's dlogits)
+    return decoder_bwd_launches(z, D1, D2, y1, dy2, B, d, hid, m_out, dD1, dc1, dD2, dc2, dz, w, nullptr, s);
+}
+
+// The decoder's backward from the gradient w.r.t. its logits on.  `extra` (nullable): side jobs of the caller that
+// ride with the first product's launch.
+static int decoder_bwd_launches(const float* z, const float* D1, const float* D2, const float* y1, const float* dy2, int B,
+                                int d, int hid, int m_out, float* dD1, float* dc1, float* dD2, float* dc2, float* dz,
+                                const DecBwdWs& w, const SideJobs* extra, hipStream_t s)
+{
     // Each weight gradient is independent of the activation gradient beside it: gemm_pair puts the two in one
-    // launch where their shapes allow.
+    // launch where their shapes allow.  The bias gradients are column sums of matrices these launches only read:
+    // dc2 rides with the first, dc1 (of dy1, which the first one writes) with the second.
+    SideJobs side2, side1;
+    if (extra != nullptr) side2 = *extra;
+    const bool riding = side2.add_colsum(dy2, B, m_out, m_out, dc2) && side1.add_colsum(w.dy1, B, hid, hid, dc1);
+    if (!riding) {
+        side2 = SideJobs();
+        if (extra != nullptr) side2 = *extra;
+    }
     GemmDesc g, ga;
     // dD2 = dy2^T * y1
     g.A = dy2; g.lda = m_out; g.a_kc = false;
     g.B = y1; g.ldb = hid; g.b_kc = false;
     g.C = dD2; g.ldc = hid; g.M = m_out; g.N = hid; g.K = B;
     g.splits = gemm_pick_splits(m_out, hid, B, 1); g.slabs = w.slabs;
+    if (side2.blocks() > 0) g.side = &side2;
     // dy1 = (dy2 * D2) masked by relu
     ga.A = dy2; ga.lda = m_out; ga.a_kc = true;
     ga.B = D2; ga.ldb = hid; ga.b_kc = false;
@@ -870,14 +911,94 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
     g.B = z; g.ldb = d; g.b_kc = false;
     g.C = dD1; g.ldc = d; g.M = hid; g.N = d; g.K = B;
     g.splits = gemm_pick_splits(hid, d, B, 1); g.slabs = w.slabs;
+    if (riding) g.side = &side1;
     // dz = dy1 * D1
     ga = GemmDesc();
     ga.A = w.dy1; ga.lda = hid; ga.a_kc = true;
     ga.B = D1; ga.ldb = d; ga.b_kc = false;
     ga.C = dz; ga.ldc = d; ga.M = B; ga.N = d; ga.K = hid;
     GTG_TRY(gemm_pair(g, ga, s));
-    // both bias gradients in one launch: dc2 = column sums of dy2, dc1 of dy1
+    if (riding) return GTG_OK;
+    // (more than 1024 graphs) both bias gradients in a launch of their own
     return colsum_pair(dy2, B, m_out, m_out, dc2, w.dy1, B, hid, hid, dc1, w.cs, s);
+}
+
+// ---------------------------------------------------------------------------
+// Latent head + decoder + reconstruction loss, forward and backward, as one call: the launches of
+// gtg_latent_fwd, gtg_decoder_fwd, gtg_bce_loss_fwd, gtg_decoder_bwd and gtg_latent_bwd in that order, except that
+// what those calls must finish inside their own boundaries rides here in launches that follow: the final sums of
+// the two loss terms and (optionally) Adam's step-counter kernel become side jobs of the decoder's first
+// weight-gradient launch.  Every output is bit-identical to the five calls'.
+// ---------------------------------------------------------------------------
+struct HeadWs {
+    float *klp, *bcep, *dboth, *cs, *slabs;
+    DecBwdWs dec;
+};
+
+static void head_layout(Carver& c, int64_t B, int d, int hid, int m_out, HeadWs* w)
+{
+    w->klp = c.take<float>((size_t)reparam_kl_partials(B, d) + 1);
+    w->bcep = c.take<float>((size_t)B + 1);
+    w->dboth = c.take<float>((size_t)2 * B * d);
+    w->cs = reinterpret_cast<float*>(c.take<char>(colsum_workspace(B, d)));
+    w->slabs = reinterpret_cast<float*>(c.take<char>(gemm_splitk_workspace(d, d, (int)B, 1)));
+    dec_bwd_layout(c, B, d, hid, m_out, &w->dec);
+}
+
+size_t gtg_head_workspace_bytes(int64_t num_graphs, int n, int d, int hid)
+{
+    Carver c(nullptr, 0);
+    HeadWs w;
+    head_layout(c, num_graphs, d, hid, n * (n + 1) / 2, &w);
+    return c.off;
+}
+
+int gtg_head_fwd_bwd(const float* h, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
+                     const float* D1, const float* c1, const float* D2, const float* c2, const float* eps,
+                     const float* adj_target, int64_t num_graphs, int n, int d, int hid, const float* kl_w_dev,
+                     const float* gscale_dev, float* mu, float* logvar, float* z, float* y1, float* out, float* dlogits,
+                     float* loss, float* kl, float* dWmu, float* dbmu, float* dWlv, float* dblv, float* dD1, float* dc1,
+                     float* dD2, float* dc2, float* dz, float* dh, void* adam_state16, float lr, float beta1, float beta2,
+                     void* ws, size_t ws_bytes, void* stream)
+{
+    GTG_REQUIRE(num_graphs >= 1 && n >= 1 && d >= 1 && hid >= 1, "bad size");
+    GTG_REQUIRE(h && Wmu && bmu && Wlv && blv && D1 && c1 && D2 && c2 && eps && adj_target, "null input");
+    GTG_REQUIRE(mu && logvar && z && y1 && out && dlogits && loss && kl, "null output");
+    GTG_REQUIRE(dWmu && dbmu && dWlv && dblv && dD1 && dc1 && dD2 && dc2 && dz && dh, "null gradient");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)num_graphs;
+    const int m_out = n * (n + 1) / 2;
+    Carver c(ws, ws_bytes);
+    HeadWs w;
+    head_layout(c, B, d, hid, m_out, &w);
+    if (c.overflow || ws == nullptr) return set_error(GTG_ERR_WORKSPACE, "gtg_head_fwd_bwd: workspace too small");
+
+    // ---- forward
+    GemmDesc g;
+    g.A = h; g.lda = d; g.B = Wmu; g.ldb = d; g.C = mu; g.ldc = d;
+    g.M = B; g.N = d; g.K = d; g.bias = bmu;
+    g.batch = 2; g.strideA = 0; g.strideB = Wlv - Wmu; g.strideC = logvar - mu; g.strideBias = blv - bmu;
+    GTG_TRY(gemm(g, s));
+    GTG_TRY(reparam_kl(mu, logvar, eps, B, d, z, w.klp, nullptr, s));
+    g = GemmDesc();
+    g.A = z; g.lda = d; g.B = D1; g.ldb = d; g.C = y1; g.ldc = hid;
+    g.M = B; g.N = hid; g.K = d; g.bias = c1; g.epi = EPI_RELU;
+    GTG_TRY(gemm(g, s));
+    g = GemmDesc();
+    g.A = y1; g.lda = hid; g.B = D2; g.ldb = hid; g.C = out; g.ldc = m_out;
+    g.M = B; g.N = m_out; g.K = hid; g.bias = c2; g.epi = EPI_SIGMOID;
+    GTG_TRY(gemm(g, s));
+    GTG_TRY(bce_fwd(out, adj_target, B, n, w.bcep, nullptr, dlogits, gscale_dev, s));
+
+    // ---- backward; the loss terms' final sums and Adam's step counter ride with its first launch
+    SideJobs extra;
+    bool ok = extra.add_sum(w.klp, reparam_kl_partials(B, d), reparam_kl_scale(B), kl);
+    ok = extra.add_sum(w.bcep, B, bce_scale(B, n), loss) && ok;
+    if (adam_state16 != nullptr) ok = extra.add_adam_prepare(adam_state16, lr, beta1, beta2) && ok;
+    if (!ok) return set_error(GTG_ERR_LAUNCH, "gtg_head_fwd_bwd: side job list full");
+    GTG_TRY(decoder_bwd_launches(z, D1, D2, y1, dlogits, B, d, hid, m_out, dD1, dc1, dD2, dc2, dz, w.dec, &extra, s));
+    return latent_bwd_launches(h, Wmu, Wlv, mu, logvar, eps, dz, 1.f, kl_w_dev, B, d, dWmu, dbmu, dWlv, dblv, dh,
+                               w.dboth, w.cs, w.slabs, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -1026,8 +1147,17 @@ int gtg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 {
     GTG_REQUIRE(numel >= 0, "negative size");
     GTG_REQUIRE(state16 && (numel == 0 || (param && grad && exp_avg && exp_avg_sq)), "null pointer");
-    return adam_stateful(param, grad, exp_avg, exp_avg_sq, numel, state16, lr, beta1, beta2, eps, grad_scale,
+    return adam_stateful(param, grad, exp_avg, exp_avg_sq, numel, state16, lr, beta1, beta2, eps, grad_scale, false,
                          (hipStream_t)stream);
+}
+
+int gtg_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                    const void* state16, float beta1, float beta2, float eps, float grad_scale, void* stream)
+{
+    GTG_REQUIRE(numel >= 0, "negative size");
+    GTG_REQUIRE(state16 && (numel == 0 || (param && grad && exp_avg && exp_avg_sq)), "null pointer");
+    return adam_stateful(param, grad, exp_avg, exp_avg_sq, numel, const_cast<void*>(state16), 0.f, beta1, beta2, eps,
+                         grad_scale, true, (hipStream_t)stream);
 }
 
 // Plain GEMM entry (tests, and callers that want one of the three layouts).

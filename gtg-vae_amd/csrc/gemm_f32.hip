@@ -1286,15 +1286,40 @@ struct GemmJob {
     }
 };
 
+// The first sj.blocks() blocks of the launch run side jobs (side_jobs.h): short reductions that do not depend on
+// the products, placed in front so that they are dispatched first and are gone by the time the products' blocks
+// need their slots.
 template <class J0, class J1>
-__global__ __launch_bounds__(J0::THREADS) void gemm_pair_kernel(const KArgs a0, const KArgs a1, const int n0)
+__global__ __launch_bounds__(J0::THREADS) void gemm_pair_kernel(const KArgs a0, const KArgs a1, const int n0,
+                                                                const SideJobs sj)
 {
     static_assert(J0::THREADS == J1::THREADS, "the jobs of a pair share the block size");
-    __shared__ __attribute__((aligned(16))) float smem[J0::SMEM > J1::SMEM ? J0::SMEM : J1::SMEM];
-    if ((int)blockIdx.x < n0)
-        J0::run(a0, smem, (int)blockIdx.x, n0);
+    constexpr int SMEM = J0::SMEM > J1::SMEM ? J0::SMEM : J1::SMEM;
+    static_assert(SMEM >= SIDE_SMEM_FLOATS, "the side jobs stage through the products' LDS");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    const int ns = sj.first_block[SIDE_MAX_JOBS];
+    const int bx = (int)blockIdx.x - ns;
+    if (bx < 0)
+        side_run<J0::THREADS>(sj, (int)blockIdx.x, smem);
+    else if (bx < n0)
+        J0::run(a0, smem, bx, n0);
     else
-        J1::run(a1, smem, (int)blockIdx.x - n0, (int)gridDim.x - n0);
+        J1::run(a1, smem, bx - n0, (int)gridDim.x - ns - n0);
+}
+
+// One batch-sized product (a K-group configuration, fp32 pipe) with side jobs in front of its blocks.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_side_kernel(const KArgs a, const SideJobs sj)
+{
+    constexpr int SMEM = gemm_smem_floats<BM, BN, WAVES_M, WAVES_N, KG, AKC, BKC, 0>();
+    static_assert(SMEM >= SIDE_SMEM_FLOATS, "the side jobs stage through the product's LDS");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    const int ns = sj.first_block[SIDE_MAX_JOBS];
+    const int bx = (int)blockIdx.x - ns;
+    if (bx < 0)
+        side_run<64 * WAVES_M * WAVES_N * KG>(sj, (int)blockIdx.x, smem);
+    else
+        gemm_body<BM, BN, WAVES_M, WAVES_N, KG, AKC, BKC, 0>(a, smem, bx, (int)gridDim.x - ns);
 }
 
 // C (+)= sum over slabs, in slab order.
@@ -1435,6 +1460,21 @@ int launch_cfg(const KArgs& k, bool akc, bool bkc, int grid, hipStream_t s)
     else
         return set_error(GTG_ERR_UNSUPPORTED, "gemm: A M-contiguous with B K-contiguous is not instantiated");
     return check_launch("gemm_kernel");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KG>
+int launch_cfg_side(const KArgs& k, const SideJobs& sj, bool akc, bool bkc, int grid, hipStream_t s)
+{
+    const dim3 block(64 * WAVES_M * WAVES_N * KG), g(grid + sj.blocks());
+    if (akc && bkc)
+        hipLaunchKernelGGL((gemm_side_kernel<BM, BN, WAVES_M, WAVES_N, KG, true, true>), g, block, 0, s, k, sj);
+    else if (akc && !bkc)
+        hipLaunchKernelGGL((gemm_side_kernel<BM, BN, WAVES_M, WAVES_N, KG, true, false>), g, block, 0, s, k, sj);
+    else if (!akc && !bkc)
+        hipLaunchKernelGGL((gemm_side_kernel<BM, BN, WAVES_M, WAVES_N, KG, false, false>), g, block, 0, s, k, sj);
+    else
+        return set_error(GTG_ERR_UNSUPPORTED, "gemm: A M-contiguous with B K-contiguous is not instantiated");
+    return check_launch("gemm_side_kernel");
 }
 
 // C = A B^T with both operands given as three bf16 planes (GemmDesc::planes).
@@ -1655,6 +1695,12 @@ int gemm(const GemmDesc& d, hipStream_t s)
 {
     GemmPlan p;
     if (int rc = gemm_plan(d, p)) return rc;
+    const bool has_side = d.side != nullptr && d.side->blocks() > 0;
+    // side jobs ride in the launch of a K-group configuration; in front of any other product they run alone
+    const bool carry = has_side && !p.empty && p.splits == 1 && (p.cfg == CFG_64_K2 || p.cfg == CFG_32_K4) &&
+                       p.grid + d.side->blocks() <= 0x7fffffffLL;
+    if (has_side && !carry)
+        if (int rc = side_jobs_launch(*d.side, s)) return rc;
     if (p.empty) return GTG_OK;
     const KArgs& k = p.k;
     const TileCfg cfg = p.cfg;
@@ -1727,8 +1773,14 @@ int gemm(const GemmDesc& d, hipStream_t s)
             else
                 rc = launch_cfg<256, 128, 4, 2, 1, 1>(k, d.a_kc, d.b_kc, (int)grid, s);
             break;
-        case CFG_64_K2: rc = launch_cfg<64, 64, 2, 2, 2>(k, d.a_kc, d.b_kc, (int)grid, s); break;
-        case CFG_32_K4: rc = launch_cfg<32, 32, 1, 1, 4>(k, d.a_kc, d.b_kc, (int)grid, s); break;
+        case CFG_64_K2:
+            rc = carry ? launch_cfg_side<64, 64, 2, 2, 2>(k, *d.side, d.a_kc, d.b_kc, (int)grid, s)
+                       : launch_cfg<64, 64, 2, 2, 2>(k, d.a_kc, d.b_kc, (int)grid, s);
+            break;
+        case CFG_32_K4:
+            rc = carry ? launch_cfg_side<32, 32, 1, 1, 4>(k, *d.side, d.a_kc, d.b_kc, (int)grid, s)
+                       : launch_cfg<32, 32, 1, 1, 4>(k, d.a_kc, d.b_kc, (int)grid, s);
+            break;
         default: rc = launch_cfg<64, 64, 2, 2, 1>(k, d.a_kc, d.b_kc, (int)grid, s); break;
     }
     if (rc != GTG_OK) return rc;
@@ -1755,11 +1807,15 @@ int gemm_pair(const GemmDesc& d0, const GemmDesc& d1, hipStream_t s)
         if (int rc = gemm(d0, s)) return rc;
         return gemm(d1, s);
     }
+    if (d1.side != nullptr && d1.side->blocks() > 0)
+        if (int rc = side_jobs_launch(*d1.side, s)) return rc;
+    SideJobs sj;
+    if (d0.side != nullptr) sj = *d0.side;
     ProfScope prof(s, "gemm_pair32k4_tn+nn", (long long)d0.M * d0.batch, d0.N, d0.K);
     using J0 = GemmJob<32, 32, 1, 1, 4, false, false>;
     using J1 = GemmJob<32, 32, 1, 1, 4, true, false>;
-    hipLaunchKernelGGL((gemm_pair_kernel<J0, J1>), dim3((unsigned)(p0.grid + p1.grid)), dim3(J0::THREADS), 0, s, p0.k,
-                       p1.k, (int)p0.grid);
+    hipLaunchKernelGGL((gemm_pair_kernel<J0, J1>), dim3((unsigned)(p0.grid + p1.grid + sj.blocks())), dim3(J0::THREADS), 0,
+                       s, p0.k, p1.k, (int)p0.grid, sj);
     return check_launch("gemm_pair_kernel");
 }
 

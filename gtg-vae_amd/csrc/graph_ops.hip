@@ -898,13 +898,6 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
 // Adam (torch.optim.Adam arithmetic, no weight decay / amsgrad).
 // state: [0] step (as float bits of an int32), [1] lr/bc1, [2] 1/sqrt(bc2)
 // ---------------------------------------------------------------------------
-struct AdamState {
-    int32_t step;
-    float step_size;
-    float inv_sqrt_bc2;
-    float pad;
-};
-
 __global__ void adam_prepare_kernel(AdamState* st, float lr, float b1, float b2)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -949,6 +942,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             p[i] = p[i] - step_size * (me / (sqrtf(ve) * isb + eps));
         }
     }
+}
+
+// The side jobs of side_jobs.h as a launch of their own, for the cases where no GEMM launch can carry them.
+__global__ __launch_bounds__(256) void side_jobs_kernel(const SideJobs sj)
+{
+    __shared__ __attribute__((aligned(16))) float smem[SIDE_SMEM_FLOATS];
+    side_run<256>(sj, (int)blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -1145,8 +1145,8 @@ int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B
         int rc = check_launch("reparam_kl_kernel");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, kl_partial, nb, B > 0 ? -0.5f / (float)B : 0.f,
-                       kl_out);
+    if (kl_out == nullptr) return GTG_OK;  // the caller sums the nb partials itself (reparam_kl_partials)
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, kl_partial, nb, reparam_kl_scale(B), kl_out);
     return check_launch("final_sum_kernel");
 }
 
@@ -1170,8 +1170,8 @@ int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_par
         int rc = check_launch("bce_fwd_kernel");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, row_partial, B,
-                       (B > 0 && m > 0) ? 1.f / ((float)B * (float)m) : 0.f, loss);
+    if (loss == nullptr) return GTG_OK;  // the caller sums the B partials itself
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, row_partial, B, bce_scale(B, n), loss);
     return check_launch("final_sum_kernel");
 }
 
@@ -1227,6 +1227,13 @@ int bce_bwd(const float* out, const float* adj, int64_t B, int n, const float* g
     hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)B), dim3(256), 0, s, out, adj, n, m, gdev,
                        gscale / ((float)B * (float)m), through_sigmoid, dy2);
     return check_launch("bce_bwd_kernel");
+}
+
+int side_jobs_launch(const SideJobs& sj, hipStream_t s)
+{
+    if (sj.blocks() == 0) return GTG_OK;
+    hipLaunchKernelGGL(side_jobs_kernel, dim3((unsigned)sj.blocks()), dim3(256), 0, s, sj);
+    return check_launch("side_jobs_kernel");
 }
 
 int graph_meta(const int32_t* extent, const float* adj, int64_t B, int n, int32_t* meta, float* adjc, int32_t* zero,
@@ -1302,11 +1309,14 @@ int sigmoid_bwd(const float* out, const float* dout, int64_t total, float* dy, h
 }
 
 int adam_stateful(float* p, const float* g, float* m, float* v, int64_t n, void* state, float lr, float b1, float b2,
-                  float eps, float gscale, hipStream_t s)
+                  float eps, float gscale, bool prepared, hipStream_t s)
 {
     AdamState* st = reinterpret_cast<AdamState*>(state);
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, st, lr, b1, b2);
-    int rc = check_launch("adam_prepare_kernel");
+    int rc = GTG_OK;
+    if (!prepared) {
+        hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, st, lr, b1, b2);
+        rc = check_launch("adam_prepare_kernel");
+    }
     if (rc || n == 0) return rc;
     const int64_t nv = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, st, b1, b2, eps,

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/gtgvae.h"  // GTG_OK / GTG_ERR_* codes
+#include "side_jobs.h"
 
 namespace gtg {
 
@@ -99,6 +100,10 @@ struct GemmDesc {
     // absmax_ws already holds partial maxima that bound A (left by an earlier product on the same or a larger
     // array): only B is walked
     bool a_partials_ready = false;
+    // Side jobs (side_jobs.h) that neither read what this product writes nor write what it reads: they ride in
+    // extra blocks of its launch when the launch is one of the K-group configurations (batch-sized products) and
+    // run as a launch of their own in front of it otherwise.  gemm_pair takes those of its first product.
+    const SideJobs* side = nullptr;
 };
 constexpr int GEMM_ABSMAX_PARTS = 1024;
 constexpr size_t GEMM_ABSMAX_BYTES = 2 * GEMM_ABSMAX_PARTS * sizeof(float);
@@ -216,14 +221,24 @@ int pool_bwd_gather_planes(const float* adj, const float* dpool, const int32_t* 
                            int n, int d, long long rows_alloc, void* planes, float* proto_rows, float* pg_partial,
                            int32_t* zero, int zero_count, const float* w, int w_rows, int w_cols, int w_ld, void* w_planes,
                            float* inv_rows, float* inv_w, hipStream_t s);
+// kl_out = reparam_kl_scale(B) * (the reparam_kl_partials(B, d) partial sums, added by final_sum_kernel); with
+// kl_out == NULL the partials are left for the caller to sum (a SIDE_SUM job)
 int reparam_kl(const float* mu, const float* logvar, const float* eps, int64_t B, int d, float* z,
                float* kl_partial, float* kl_out, hipStream_t s);
+inline long long reparam_kl_partials(int64_t B, int d) { return ((long long)B * d + 255) / 256; }
+inline float reparam_kl_scale(int64_t B) { return B > 0 ? -0.5f / (float)B : 0.f; }
 // dmu / dlogvar rows have stride ld_out (d, or 2d when they are the two halves of one (B, 2d) matrix)
 int latent_bwd_elem(const float* dz, const float* mu, const float* logvar, const float* eps, const float* kl_scale_dev,
                     float kl_scale, int64_t B, int d, int ld_out, float* dmu, float* dlogvar, hipStream_t s);
 // dlogits (nullable): gradient of the mean loss w.r.t. the pre-sigmoid logits, written in the same pass
+// loss = bce_scale(B, n) * (the B per-graph partial sums); with loss == NULL the partials are left for the caller
 int bce_fwd(const float* out, const float* adj, int64_t B, int n, float* row_partial, float* loss, float* dlogits,
             const float* gscale_dev, hipStream_t s);
+inline float bce_scale(int64_t B, int n)
+{
+    const int m = n * (n + 1) / 2;
+    return (B > 0 && m > 0) ? 1.f / ((float)B * (float)m) : 0.f;
+}
 // the same with the per-graph partial sums in a file-scope device array (no workspace argument, nothing allocated)
 int bce_fwd_static(const float* out, const float* adj, int64_t B, int n, float* loss, float* dlogits,
                    const float* gscale_dev, hipStream_t s);
@@ -237,8 +252,9 @@ int bce_bwd(const float* out, const float* adj, int64_t B, int n, const float* g
 int sigmoid_bwd(const float* out, const float* dout, int64_t total, float* dy, hipStream_t s);
 // state: 16 device bytes {int32 step, float lr/bc1, float 1/sqrt(bc2), pad}; the
 // step counter lives on the device so a captured HIP graph can be replayed.
+// prepared: the step counter and bias corrections of this step were already advanced (a SIDE_ADAM_PREPARE job)
 int adam_stateful(float* p, const float* g, float* m, float* v, int64_t n, void* state, float lr, float b1, float b2,
-                  float eps, float gscale, hipStream_t s);
+                  float eps, float gscale, bool prepared, hipStream_t s);
 int edge_prf(const int32_t* edges, const int32_t* count, const uint64_t* gold_bits, int64_t G, int n,
              float* recall, float* precision, hipStream_t s);
 

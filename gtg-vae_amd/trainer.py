@@ -182,7 +182,7 @@ class GraphVAETrainer:
         self.dh = torch.empty((B, d), **f32)
         nbytes = max(L.gtg_encoder_compact_fwd_workspace_bytes(B, n, d), L.gtg_encoder_compact_bwd_workspace_bytes(B, n, d),
                      L.gtg_latent_workspace_bytes(B, d), L.gtg_decoder_bwd_workspace_bytes(B, d, hid, m),
-                     L.gtg_bce_workspace_bytes(B))
+                     L.gtg_bce_workspace_bytes(B), L.gtg_head_workspace_bytes(B, n, d, hid))
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._cap_B, self._cap_E = B, E
         self.drop_graphs()       # they hold the old buffers' addresses
@@ -256,7 +256,9 @@ class GraphVAETrainer:
     # The step is three runs of launches with the two gradient all-reduces between
     # them; each run can be replayed as a HIP graph while the collectives stay
     # ordinary stream work.
-    def _seg_forward(self, B: int, stream: int, backward: bool = True):
+    def _seg_forward(self, B: int, stream: int, backward: bool = True, update: bool = False):
+        """Forward pass; with ``backward`` also the backward of the decoder and the latent head (their
+        gradients, bucket 0, are final after this), and with ``update`` the advance of Adam's step counter."""
         L, n, d, hid, m = self.L, self.n, self.d, self.hid, self.m
         p = self.p
         ws, wsn = ptr(self.ws), self.ws.numel()
@@ -270,31 +272,30 @@ class GraphVAETrainer:
                                         ptr(p["encoder.conv2.bias"]), B, n, d, ptr(meta), ptr(self.adjc), ptr(self.h1),
                                         ptr(self.pooled), ptr(self.argmax), self.matrix_mode, ws, wsn, stream),
               "gtg_encoder_compact_fwd")
+        if backward:
+            # latent head, decoder and loss, forward and backward, as one call: the loss terms' final sums and
+            # Adam's step-counter kernel ride in a later launch of the call instead of being launches themselves
+            g = self.g
+            check(L.gtg_head_fwd_bwd(
+                ptr(self.pooled), ptr(p["zg_mu.weight"]), ptr(p["zg_mu.bias"]), ptr(p["zg_var.weight"]),
+                ptr(p["zg_var.bias"]), ptr(p["decoder.decode_1.weight"]), ptr(p["decoder.decode_1.bias"]),
+                ptr(p["decoder.decode_2.weight"]), ptr(p["decoder.decode_2.bias"]), ptr(self.eps_buf), ptr(self.target),
+                B, n, d, hid, ptr(self.kl_w_dev), self.kl_w_dev[1:].data_ptr(), ptr(self.mu), ptr(self.logvar),
+                ptr(self.z), ptr(self.y1), ptr(self.out), ptr(self.dlogits), self.scalars.data_ptr(),
+                self.scalars[1:].data_ptr(), ptr(g["zg_mu.weight"]), ptr(g["zg_mu.bias"]), ptr(g["zg_var.weight"]),
+                ptr(g["zg_var.bias"]), ptr(g["decoder.decode_1.weight"]), ptr(g["decoder.decode_1.bias"]),
+                ptr(g["decoder.decode_2.weight"]), ptr(g["decoder.decode_2.bias"]), ptr(self.dz), ptr(self.dh),
+                ptr(self.adam_state) if update else None, self.lr, self.betas[0], self.betas[1], ws, wsn, stream),
+                "gtg_head_fwd_bwd")
+            return
         check(L.gtg_latent_fwd(ptr(self.pooled), ptr(p["zg_mu.weight"]), ptr(p["zg_mu.bias"]), ptr(p["zg_var.weight"]),
                                ptr(p["zg_var.bias"]), ptr(self.eps_buf), B, d, ptr(self.mu), ptr(self.logvar),
                                ptr(self.z), self.scalars[1:].data_ptr(), ws, wsn, stream), "gtg_latent_fwd")
         check(L.gtg_decoder_fwd(ptr(self.z), ptr(p["decoder.decode_1.weight"]), ptr(p["decoder.decode_1.bias"]),
                                 ptr(p["decoder.decode_2.weight"]), ptr(p["decoder.decode_2.bias"]), B, d, hid, m,
                                 ptr(self.y1), ptr(self.out), stream), "gtg_decoder_fwd")
-        # with a backward to follow, the loss kernel leaves its gradient w.r.t. the logits on the way
-        check(L.gtg_bce_loss_fwd(ptr(self.out), ptr(self.target), B, n, self.scalars.data_ptr(),
-                                 ptr(self.dlogits) if backward else None, self.kl_w_dev[1:].data_ptr(), ws, wsn,
-                                 stream), "gtg_bce_loss_fwd")
-
-    def _seg_head_backward(self, B: int, stream: int):
-        """Decoder and latent head: their gradients (bucket 0) are final after this."""
-        L, n, d, hid, m = self.L, self.n, self.d, self.hid, self.m
-        p, g = self.p, self.g
-        ws, wsn = ptr(self.ws), self.ws.numel()
-        check(L.gtg_decoder_bwd(ptr(self.z), ptr(p["decoder.decode_1.weight"]), ptr(p["decoder.decode_2.weight"]),
-                                ptr(self.y1), None, ptr(self.dlogits), None, n, 1.0, None, B, d, hid, m,
-                                ptr(g["decoder.decode_1.weight"]), ptr(g["decoder.decode_1.bias"]),
-                                ptr(g["decoder.decode_2.weight"]), ptr(g["decoder.decode_2.bias"]), ptr(self.dz), ws,
-                                wsn, stream), "gtg_decoder_bwd")
-        check(L.gtg_latent_bwd(ptr(self.pooled), ptr(p["zg_mu.weight"]), ptr(p["zg_var.weight"]), ptr(self.mu),
-                               ptr(self.logvar), ptr(self.eps_buf), ptr(self.dz), 1.0, ptr(self.kl_w_dev), B, d,
-                               ptr(g["zg_mu.weight"]), ptr(g["zg_mu.bias"]), ptr(g["zg_var.weight"]),
-                               ptr(g["zg_var.bias"]), ptr(self.dh), ws, wsn, stream), "gtg_latent_bwd")
+        check(L.gtg_bce_loss_fwd(ptr(self.out), ptr(self.target), B, n, self.scalars.data_ptr(), None,
+                                 self.kl_w_dev[1:].data_ptr(), ws, wsn, stream), "gtg_bce_loss_fwd")
 
     def _seg_encoder_backward(self, B: int, stream: int):
         L, n, d = self.L, self.n, self.d
@@ -306,18 +307,24 @@ class GraphVAETrainer:
                                         ptr(g["encoder.conv2.lin.weight"]), ptr(g["encoder.conv2.bias"]), self.matrix_mode,
                                         ptr(self.ws), self.ws.numel(), stream), "gtg_encoder_compact_bwd")
 
-    def _seg_adam(self, stream: int):
+    def _seg_adam(self, stream: int, prepared: bool = False):
+        """The optimiser step; ``prepared``: this step's forward segment already advanced the step counter."""
+        if prepared:
+            check(self.L.gtg_adam_update(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                         self.numel, ptr(self.adam_state), self.betas[0], self.betas[1], self.eps,
+                                         self.buckets.scale, stream), "gtg_adam_update")
+            return
         check(self.L.gtg_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                    self.numel, ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps,
                                    self.buckets.scale, stream), "gtg_adam_step")
 
     def _segments(self, B: int, update: bool, backward: bool = True):
         """The step as a list of callables(stream), with None where an all-reduce goes."""
-        segs = [lambda st: (self._seg_forward(B, st, backward), backward and self._seg_head_backward(B, st))]
+        segs = [lambda st: self._seg_forward(B, st, backward, backward and update)]
         if backward:
             segs += [None, lambda st: self._seg_encoder_backward(B, st)]
             if update:
-                segs += [None, lambda st: self._seg_adam(st)]
+                segs += [None, lambda st: self._seg_adam(st, prepared=True)]
         if self.world == 1:
             # no all-reduce to place between the pieces: one segment, hence one HIP graph per step
             parts = [f for f in segs if f is not None]

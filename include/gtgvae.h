@@ -240,6 +240,34 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
                     int64_t num_graphs, int d, int hid, int m_out, float* dD1, float* dc1, float* dD2, float* dc2,
                     float* dz, void* ws, size_t ws_bytes, void* stream);
 
+/* The latent head, the decoder and the reconstruction loss of one training
+ * step, forward and backward, as ONE call: what GTVAE.forward does after the
+ * encoder (src/gtvae.py:108-116: zg_mu / zg_var, reparameterize, loss_kl,
+ * decoder, GraphVAE.loss) followed by the backward of all of it
+ * (loss.backward(), src/train.py:313).  Outputs are bit-identical to
+ * gtg_latent_fwd, gtg_decoder_fwd, gtg_bce_loss_fwd(dlogits), gtg_decoder_bwd
+ * (dout = dlogits, out = NULL) and gtg_latent_bwd(kl_w = 1, kl_w_dev) run in
+ * that order; it exists because a call of its own must finish its scalars
+ * inside its own launches, while here the final sums of `loss` and `kl` ride in
+ * spare blocks of a later launch (three kernel boundaries fewer per step).
+ *   h (B, d) pooled encoder output; eps (B, d); adj_target (B, n, n);
+ *   kl_w_dev: device scalar, weight of the KL term in the backward (NULL = 1);
+ *   gscale_dev: device scalar multiplied into dlogits (NULL = 1), as in
+ *   gtg_bce_loss_fwd; loss, kl: one float each, not scaled by either.
+ *   adam_state16 (nullable): the 16-byte state of gtg_adam_step; when given,
+ *   this call advances its step counter and bias corrections (with lr, beta1,
+ *   beta2) and the step's update must then be gtg_adam_update, not
+ *   gtg_adam_step.
+ *   dz (B, d) and dh (B, d): gradients w.r.t. z and h.  m_out = n(n+1)/2. */
+size_t gtg_head_workspace_bytes(int64_t num_graphs, int n, int d, int hid);
+int gtg_head_fwd_bwd(const float* h, const float* Wmu, const float* bmu, const float* Wlv, const float* blv,
+                     const float* D1, const float* c1, const float* D2, const float* c2, const float* eps,
+                     const float* adj_target, int64_t num_graphs, int n, int d, int hid, const float* kl_w_dev,
+                     const float* gscale_dev, float* mu, float* logvar, float* z, float* y1, float* out, float* dlogits,
+                     float* loss, float* kl, float* dWmu, float* dbmu, float* dWlv, float* dblv, float* dD1, float* dc1,
+                     float* dD2, float* dc2, float* dz, float* dh, void* adam_state16, float lr, float beta1, float beta2,
+                     void* ws, size_t ws_bytes, void* stream);
+
 /* Brings one batch into the static buffers of a graph-captured step in a single
  * launch (the loop of train.py:297-312 hands the model a fresh batch every
  * iteration): the (2, num_edges) int64 edge list into a (2, edge_capacity)
@@ -376,6 +404,12 @@ int gtg_dropout(const float* x, int64_t count, float p, uint64_t seed, uint64_t 
  * sum all-reduce). */
 int gtg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, void* state16,
                   float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* The parameter update of gtg_adam_step alone, for a step whose counter and
+ * bias corrections were already advanced by gtg_head_fwd_bwd (adam_state16
+ * given there): same arithmetic, one launch. */
+int gtg_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                    const void* state16, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* ---- the fp32 MFMA GEMM underneath (exposed for tests and profiling) -------
  * C[M,N] = epilogue(op(A) op(B)); a_kc: A(m,k) at A[m*lda+k] else A[k*lda+m];

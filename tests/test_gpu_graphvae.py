@@ -290,6 +290,79 @@ def test_bce_clamp_at_the_ends(golden_dir):
     assert loss.item() == pytest.approx(float(each.astype(np.float64).mean()), rel=1e-6)
 
 
+@pytest.mark.parametrize("B,N,d,hid,adam", [(8, 10, 32, 64, True), (5, 32, 64, 96, False), (3, 64, 128, 512, True),
+                                            (512, 64, 512, 512, True), (256, 32, 256, 512, False),
+                                            (1100, 10, 32, 64, True)])
+def test_fused_head_equals_the_five_calls_bit_for_bit(B, N, d, hid, adam):
+    """gtg_head_fwd_bwd (latent head + decoder + loss, forward and backward, the scalars' final sums and Adam's
+    step counter riding in spare blocks of a later launch) against gtg_latent_fwd, gtg_decoder_fwd,
+    gtg_bce_loss_fwd, gtg_decoder_bwd, gtg_latent_bwd and gtg_adam_step's counter: every output bit-identical.
+    (The five calls are themselves checked against the oracle and the reference's goldens above and below.)
+    1100 graphs: more rows than a riding column sum takes, the stand-alone launches run instead."""
+    from gtg_vae_amd import _lib
+    from gtg_vae_amd._lib import check, ptr
+
+    L = _lib.lib()
+    m = N * (N + 1) // 2
+    g = torch.Generator().manual_seed(B * 7 + N)
+    dev = "cuda"
+    rnd = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(dev)
+    h, eps = rnd(B, d), rnd(B, d)
+    W = rnd(2 * d, d, s=d ** -0.5)                     # [Wmu; Wlv] back to back, as the trainer keeps them
+    Wmu, Wlv = W[:d], W[d:]
+    bmu, blv = rnd(d, s=0.1), rnd(d, s=0.1)
+    D1, c1, D2, c2 = rnd(hid, d, s=d ** -0.5), rnd(hid, s=0.1), rnd(m, hid, s=hid ** -0.5), rnd(m, s=0.1)
+    target = (torch.rand(B, N, N, generator=g) < 0.1).float().to(dev)
+    klw = torch.tensor([0.37, 0.8], device=dev)        # [KL weight, shard weight of the reconstruction gradient]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def outputs():
+        f = lambda *shape: torch.full(shape, float("nan"), device=dev)
+        return dict(mu=f(B, d), lv=f(B, d), z=f(B, d), y1=f(B, hid), out=f(B, m), dl=f(B, m), sc=f(2),
+                    dW=f(2 * d, d), dbmu=f(d), dblv=f(d), dD1=f(hid, d), dc1=f(hid), dD2=f(m, hid), dc2=f(m),
+                    dz=f(B, d), dh=f(B, d), adam=torch.zeros(4, device=dev))
+
+    nb = max(L.gtg_latent_workspace_bytes(B, d), L.gtg_decoder_bwd_workspace_bytes(B, d, hid, m),
+             L.gtg_bce_workspace_bytes(B), L.gtg_head_workspace_bytes(B, N, d, hid))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    lr, b1, b2 = 1e-3, 0.5, 0.999
+    a = outputs()
+    check(L.gtg_latent_fwd(ptr(h), ptr(Wmu), ptr(bmu), ptr(Wlv), ptr(blv), ptr(eps), B, d, ptr(a["mu"]), ptr(a["lv"]),
+                           ptr(a["z"]), a["sc"][1:].data_ptr(), ptr(ws), nb, st), "latent_fwd")
+    check(L.gtg_decoder_fwd(ptr(a["z"]), ptr(D1), ptr(c1), ptr(D2), ptr(c2), B, d, hid, m, ptr(a["y1"]), ptr(a["out"]), st),
+          "decoder_fwd")
+    check(L.gtg_bce_loss_fwd(ptr(a["out"]), ptr(target), B, N, ptr(a["sc"]), ptr(a["dl"]), klw[1:].data_ptr(), ptr(ws), nb,
+                             st), "bce")
+    check(L.gtg_decoder_bwd(ptr(a["z"]), ptr(D1), ptr(D2), ptr(a["y1"]), None, ptr(a["dl"]), None, N, 1.0, None, B, d, hid,
+                            m, ptr(a["dD1"]), ptr(a["dc1"]), ptr(a["dD2"]), ptr(a["dc2"]), ptr(a["dz"]), ptr(ws), nb, st),
+          "decoder_bwd")
+    check(L.gtg_latent_bwd(ptr(h), ptr(Wmu), ptr(Wlv), ptr(a["mu"]), ptr(a["lv"]), ptr(eps), ptr(a["dz"]), 1.0, ptr(klw), B,
+                           d, ptr(a["dW"][:d]), ptr(a["dbmu"]), ptr(a["dW"][d:]), ptr(a["dblv"]), ptr(a["dh"]), ptr(ws),
+                           nb, st), "latent_bwd")
+    if adam:   # the counter and bias corrections as gtg_adam_step leaves them (no elements to update)
+        check(L.gtg_adam_step(None, None, None, None, 0, ptr(a["adam"]), lr, b1, b2, 1e-8, 1.0, st), "adam_step")
+    torch.cuda.synchronize()
+    for rep in range(2):          # twice: nothing the call leaves in its workspace may matter to the next one
+        b = outputs()
+        if rep == 1 and adam:
+            b["adam"].copy_(a["adam"])
+            check(L.gtg_adam_step(None, None, None, None, 0, ptr(a["adam"]), lr, b1, b2, 1e-8, 1.0, st), "adam_step")
+        before = L.gtg_launch_count()
+        check(L.gtg_head_fwd_bwd(ptr(h), ptr(Wmu), ptr(bmu), ptr(Wlv), ptr(blv), ptr(D1), ptr(c1), ptr(D2), ptr(c2),
+                                 ptr(eps), ptr(target), B, N, d, hid, ptr(klw), klw[1:].data_ptr(), ptr(b["mu"]),
+                                 ptr(b["lv"]), ptr(b["z"]), ptr(b["y1"]), ptr(b["out"]), ptr(b["dl"]), ptr(b["sc"]),
+                                 b["sc"][1:].data_ptr(), ptr(b["dW"][:d]), ptr(b["dbmu"]), ptr(b["dW"][d:]), ptr(b["dblv"]),
+                                 ptr(b["dD1"]), ptr(b["dc1"]), ptr(b["dD2"]), ptr(b["dc2"]), ptr(b["dz"]), ptr(b["dh"]),
+                                 ptr(b["adam"]) if adam else None, lr, b1, b2, ptr(ws), nb, st), "head")
+        launches = L.gtg_launch_count() - before
+        torch.cuda.synchronize()
+        for k in a:
+            assert not torch.isnan(b[k]).any(), k
+            assert torch.equal(a[k], b[k]), (rep, k, (a[k] - b[k]).abs().max().item())
+        if 256 <= B <= 1024:      # batch sizes whose weight-gradient launches carry the side jobs
+            assert launches <= 10, launches
+
+
 @pytest.mark.parametrize("B,N,d,hid", CONFIGS)
 def test_module_step_matches_oracle(B, N, d, hid):
     """GTVAE(text=False).forward/backward through autograd == oracle."""
