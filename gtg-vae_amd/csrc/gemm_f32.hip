@@ -489,6 +489,23 @@ __device__ __forceinline__ f32x16 mfma_16bit(bf16x8 x, bf16x8 y, f32x16 c)
 // planes, three products per k step (v_mfma_f32_32x32x16_f16), the result scaled back.
 // LDS floats of one block: the operand double buffers of every wave group, reused by the epilogue to
 // stage the accumulators.
+// Operand buffers per wave group: two (the next tile is staged while the current one is multiplied), except where
+// a K group is a single wave -- its buffer is private to the wave, LDS executes a wave's accesses in order, so
+// one buffer needs no barrier at all and half the LDS lets twice as many blocks share a CU.
+template <int WAVES_M, int WAVES_N, int KG, int PREC>
+constexpr int gemm_group_buffers()
+{
+    return (PREC == 0 && KG > 1 && WAVES_M * WAVES_N == 1) ? 1 : 2;
+}
+
+// Waves per SIMD the register allocation must leave room for: four where a K group is one wave, so that four
+// blocks of four waves share a CU (their LDS allows it).
+template <int WAVES_M, int WAVES_N, int KG, int PREC>
+constexpr int gemm_min_waves()
+{
+    return (PREC == 0 && KG > 1 && WAVES_M * WAVES_N == 1) ? 4 : 1;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC, int PREC>
 constexpr int gemm_smem_floats()
 {
@@ -500,7 +517,7 @@ constexpr int gemm_smem_floats()
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int MAIN = (PREC == 4)   ? PlaneStage<BM, BN, 3>::STAGES * PlaneStage<BM, BN, 3>::STAGE_BYTES / 4
                          : (PREC == 5) ? PlaneStage<BM, BN, 2>::STAGES * PlaneStage<BM, BN, 2>::STAGE_BYTES / 4
-                                       : KG * 2 * (TA::SIZE + TB::SIZE),
+                                       : KG * gemm_group_buffers<WAVES_M, WAVES_N, KG, PREC>() * (TA::SIZE + TB::SIZE),
                   EPI = KG * WAVES_M * WAVES_N * WTM * (WTN + 4);
     // + 4: the tail split's "last arriver" word lives behind the buffers, in the same array (a second __shared__
     // object beside an array that LDS-DMA fills makes the compiler drain all loads before every LDS read).  The
@@ -527,7 +544,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
 
     // operand double buffers per wave group; reused by the epilogue to stage the accumulators
     constexpr int LDC = WTN + 4;
-    constexpr int SMEM_GROUP = 2 * (TA::SIZE + TB::SIZE);
+    constexpr int SMEM_GROUP = gemm_group_buffers<WAVES_M, WAVES_N, KG, PREC>() * (TA::SIZE + TB::SIZE);
 
     const int kg = (KG > 1) ? (int)threadIdx.x / GT : 0;
     const int tid = (KG > 1) ? (int)threadIdx.x % GT : (int)threadIdx.x;
@@ -747,6 +764,49 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
                             acc[i][j] = mfma_16bit<NPL == 2>(fa[i][pa], fb[j][sum - pa], acc[i][j]);
         }
         __syncthreads();  // the epilogue reuses the stages
+    } else if constexpr (PREC == 0 && KG > 1 && GW == 1) {
+        // A K group of one wave (32x32 tiles): the group's staging buffer is private to its wave.  LDS executes a
+        // wave's accesses in program order, so the tile written by the wave's own ds_writes is read back by its
+        // ds_reads, and overwritten by the next tile's writes, without a barrier or a second buffer: the loop has
+        // no block-wide synchronisation, the waves of a block drift freely, and with half the LDS and a ring of
+        // two prefetched tiles in registers four blocks share a CU instead of two -- these launches are 2-4 blocks
+        // per CU, so all of them start at once and the memory latency is paid once per launch, not once per round
+        // of resident blocks.  The order of the products into each accumulator is unchanged.
+        constexpr int FDEPTH = 2;
+        f32x4 ra[FDEPTH][TA::NV], rb[FDEPTH][TB::NV];
+#pragma unroll
+        for (int t = 0; t < FDEPTH; ++t) {
+            if (t < nk) {
+                TA::fetch(ra[t], A, a.lda, m0, Mr, k_begin + t * BK, k_end, a.vecA, tid);
+                TB::fetch(rb[t], B, a.ldb, n0, a.N, k_begin + t * BK, k_end, a.vecB, tid);
+            }
+        }
+        for (int kt0 = 0; kt0 < nk; kt0 += FDEPTH) {
+#pragma unroll
+            for (int u = 0; u < FDEPTH; ++u) {
+                const int kt = kt0 + u;
+                if (kt >= nk) break;  // uniform over the wave
+                TA::stage(sA0, ra[u], tid);
+                TB::stage(sB0, rb[u], tid);
+                if (kt + FDEPTH < nk) {
+                    const int k0 = k_begin + (kt + FDEPTH) * BK;
+                    TA::fetch(ra[u], A, a.lda, m0, Mr, k0, k_end, a.vecA, tid);
+                    TB::fetch(rb[u], B, a.ldb, n0, a.N, k0, k_end, a.vecB, tid);
+                }
+                f32x4 fa[BK / 8], fb[BK / 8];
+#pragma unroll
+                for (int g = 0; g < BK / 8; ++g) {
+                    fa[g] = TA::frag(sA0, wm, g, r, h);
+                    fb[g] = TB::frag(sB0, wn, g, r, h);
+                }
+#pragma unroll
+                for (int g = 0; g < BK / 8; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][e], fb[g][e], acc[0][0], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // the epilogue stages the accumulators over every group's buffer
     } else if constexpr (PREC == 0 && KG > 1) {
         // K-group configurations run batch-sized GEMMs: a block sees only a handful of k steps, each far
         // shorter than a global load's latency, so the next FDEPTH tiles wait in registers (tile t in slot
@@ -1266,7 +1326,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC, int PREC>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_kernel(const KArgs a)
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG, (gemm_min_waves<WAVES_M, WAVES_N, KG, PREC>())) void gemm_kernel(const KArgs a)
 {
     __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<BM, BN, WAVES_M, WAVES_N, KG, AKC, BKC, PREC>()];
     gemm_body<BM, BN, WAVES_M, WAVES_N, KG, AKC, BKC, PREC>(a, smem, (int)blockIdx.x, (int)gridDim.x);
@@ -1280,6 +1340,7 @@ template <int BM_, int BN_, int WM_, int WN_, int KG_, bool AKC_, bool BKC_>
 struct GemmJob {
     static constexpr int THREADS = 64 * WM_ * WN_ * KG_;
     static constexpr int SMEM = gemm_smem_floats<BM_, BN_, WM_, WN_, KG_, AKC_, BKC_, 0>();
+    static constexpr int MIN_WAVES = gemm_min_waves<WM_, WN_, KG_, 0>();
     static __device__ __forceinline__ void run(const KArgs& a, float* smem, int block_x, int grid_x)
     {
         gemm_body<BM_, BN_, WM_, WN_, KG_, AKC_, BKC_, 0>(a, smem, block_x, grid_x);
@@ -1290,8 +1351,8 @@ struct GemmJob {
 // the products, placed in front so that they are dispatched first and are gone by the time the products' blocks
 // need their slots.
 template <class J0, class J1>
-__global__ __launch_bounds__(J0::THREADS) void gemm_pair_kernel(const KArgs a0, const KArgs a1, const int n0,
-                                                                const SideJobs sj)
+__global__ __launch_bounds__(J0::THREADS, J0::MIN_WAVES) void gemm_pair_kernel(const KArgs a0, const KArgs a1, const int n0,
+                                                                               const int lead1, const SideJobs sj)
 {
     static_assert(J0::THREADS == J1::THREADS, "the jobs of a pair share the block size");
     constexpr int SMEM = J0::SMEM > J1::SMEM ? J0::SMEM : J1::SMEM;
@@ -1299,17 +1360,20 @@ __global__ __launch_bounds__(J0::THREADS) void gemm_pair_kernel(const KArgs a0, 
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     const int ns = sj.first_block[SIDE_MAX_JOBS];
     const int bx = (int)blockIdx.x - ns;
+    const int n1 = (int)gridDim.x - ns - n0;
+    // the job whose blocks run longer (the deeper K) is dispatched first, so that its blocks do not form the
+    // launch's tail; which block computes a tile changes nothing in the tile
     if (bx < 0)
         side_run<J0::THREADS>(sj, (int)blockIdx.x, smem);
-    else if (bx < n0)
-        J0::run(a0, smem, bx, n0);
+    else if (lead1 ? bx >= n1 : bx < n0)
+        J0::run(a0, smem, lead1 ? bx - n1 : bx, n0);
     else
-        J1::run(a1, smem, bx - n0, (int)gridDim.x - ns - n0);
+        J1::run(a1, smem, lead1 ? bx : bx - n0, n1);
 }
 
 // One batch-sized product (a K-group configuration, fp32 pipe) with side jobs in front of its blocks.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG) void gemm_side_kernel(const KArgs a, const SideJobs sj)
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KG, (gemm_min_waves<WAVES_M, WAVES_N, KG, 0>())) void gemm_side_kernel(const KArgs a, const SideJobs sj)
 {
     constexpr int SMEM = gemm_smem_floats<BM, BN, WAVES_M, WAVES_N, KG, AKC, BKC, 0>();
     static_assert(SMEM >= SIDE_SMEM_FLOATS, "the side jobs stage through the product's LDS");
@@ -1432,7 +1496,7 @@ inline TileCfg pick_cfg(int M, int N, int K, int batch, int epi)
     if (batch == 1 && M >= 128 && N >= 128 && t128 * (K / 1024) >= 192) return CFG_128;
     const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64) * batch;
     // few tiles: 32x32 tiles put one on every CU and four wave groups quarter the dependent K chain
-    if (K >= 256 && t64 <= 256) return CFG_32_K4;
+    if (K >= 256 && t64 <= 288) return CFG_32_K4;
     return K >= 128 ? CFG_64_K2 : CFG_64;
 }
 
@@ -1815,7 +1879,7 @@ int gemm_pair(const GemmDesc& d0, const GemmDesc& d1, hipStream_t s)
     using J0 = GemmJob<32, 32, 1, 1, 4, false, false>;
     using J1 = GemmJob<32, 32, 1, 1, 4, true, false>;
     hipLaunchKernelGGL((gemm_pair_kernel<J0, J1>), dim3((unsigned)(p0.grid + p1.grid + sj.blocks())), dim3(J0::THREADS), 0,
-                       s, p0.k, p1.k, (int)p0.grid, sj);
+                       s, p0.k, p1.k, (int)p0.grid, d1.K > d0.K ? 1 : 0, sj);
     return check_launch("gemm_pair_kernel");
 }
 
