@@ -676,7 +676,7 @@ int gtg_latent_fwd(const float* h, const float* Wmu, const float* bmu, const flo
 static int latent_bwd_launches(const float* h, const float* Wmu, const float* Wlv, const float* mu, const float* logvar,
                                const float* eps, const float* dz, float kl_w, const float* kl_w_dev, int B, int d,
                                float* dWmu, float* dbmu, float* dWlv, float* dblv, float* dh, float* dboth, float* cs,
-                               float* slabs, hipStream_t s)
+                               float* slabs, hipStream_t s, bool elem_done = false)
 {
     // When the two weight matrices lie back to back in memory, [Wmu; Wlv] is one (2d, d) operand: dmu and dlogvar
     // are then kept as the halves of (B, 2d) rows and dh = [dmu | dlogvar] [Wmu; Wlv] is a single GEMM.
@@ -685,7 +685,8 @@ static int latent_bwd_launches(const float* h, const float* Wmu, const float* Wl
     float* dmu = dboth;
     float* dlv = stacked ? dboth + d : dboth + (size_t)B * d;
 
-    GTG_TRY(latent_bwd_elem(dz, mu, logvar, eps, kl_w_dev, kl_w, B, d, ld, dmu, dlv, s));
+    // (elem_done: the product that wrote dz already left dmu and dlogvar in dboth, latent_fuse() below)
+    if (!elem_done) GTG_TRY(latent_bwd_elem(dz, mu, logvar, eps, kl_w_dev, kl_w, B, d, ld, dmu, dlv, s));
     const int splits = gemm_pick_splits(d, d, B, 1);
     GemmDesc g, gh;
     // dW = dY^T * h
@@ -844,7 +845,7 @@ size_t gtg_decoder_bwd_workspace_bytes(int64_t num_graphs, int d, int hid, int m
 
 static int decoder_bwd_launches(const float* z, const float* D1, const float* D2, const float* y1, const float* dy2, int B,
                                 int d, int hid, int m_out, float* dD1, float* dc1, float* dD2, float* dc2, float* dz,
-                                const DecBwdWs& w, const SideJobs* extra, hipStream_t s);
+                                const DecBwdWs& w, const SideJobs* extra, const GemmFuse* latent, hipStream_t s);
 
 // Exactly one of (dout) and (adj_target) is given:
 //   dout        gradient w.r.t. the decoder's sigmoid output (generic autograd path)
@@ -873,14 +874,15 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
         GTG_TRY(sigmoid_bwd(out, dout, (int64_t)B * m_out, w.dy2, s));
     else
         dy2 = dout;  // already the gradient w.r.t. the logits (gtg_bce_loss_fwd's dlogits)
-    return decoder_bwd_launches(z, D1, D2, y1, dy2, B, d, hid, m_out, dD1, dc1, dD2, dc2, dz, w, nullptr, s);
+    return decoder_bwd_launches(z, D1, D2, y1, dy2, B, d, hid, m_out, dD1, dc1, dD2, dc2, dz, w, nullptr, nullptr, s);
 }
 
 // The decoder's backward from the gradient w.r.t. its logits on.  `extra` (nullable): side jobs of the caller that
-// ride with the first product's launch.
+// ride with the first product's launch.  `latent` (nullable): the product that writes dz goes on, in its epilogue,
+// to the gradients w.r.t. mu and logvar (EPI_LATENT_BWD).
 static int decoder_bwd_launches(const float* z, const float* D1, const float* D2, const float* y1, const float* dy2, int B,
                                 int d, int hid, int m_out, float* dD1, float* dc1, float* dD2, float* dc2, float* dz,
-                                const DecBwdWs& w, const SideJobs* extra, hipStream_t s)
+                                const DecBwdWs& w, const SideJobs* extra, const GemmFuse* latent, hipStream_t s)
 {
     // Each weight gradient is independent of the activation gradient beside it: gemm_pair puts the two in one
     // launch where their shapes allow.  The bias gradients are column sums of matrices these launches only read:
@@ -917,6 +919,10 @@ static int decoder_bwd_launches(const float* z, const float* D1, const float* D2
     ga.A = w.dy1; ga.lda = hid; ga.a_kc = true;
     ga.B = D1; ga.ldb = d; ga.b_kc = false;
     ga.C = dz; ga.ldc = d; ga.M = B; ga.N = d; ga.K = hid;
+    if (latent != nullptr) {
+        ga.epi = EPI_LATENT_BWD;
+        ga.fuse = *latent;
+    }
     GTG_TRY(gemm_pair(g, ga, s));
     if (riding) return GTG_OK;
     // (more than 1024 graphs) both bias gradients in a launch of their own
@@ -938,7 +944,10 @@ struct HeadWs {
 static void head_layout(Carver& c, int64_t B, int d, int hid, int m_out, HeadWs* w)
 {
     w->klp = c.take<float>((size_t)reparam_kl_partials(B, d) + 1);
-    w->bcep = c.take<float>((size_t)B + 1);
+    // loss partials: one per graph (bce_fwd_kernel) or one per wave of the decoder's last product (at most four
+    // per 32x32 outputs: gemm_bce_partials)
+    const size_t tiles = 4 * (size_t)((B + 31) / 32) * (size_t)((m_out + 31) / 32);
+    w->bcep = c.take<float>((tiles > (size_t)B ? tiles : (size_t)B) + 1);
     w->dboth = c.take<float>((size_t)2 * B * d);
     w->cs = reinterpret_cast<float*>(c.take<char>(colsum_workspace(B, d)));
     w->slabs = reinterpret_cast<float*>(c.take<char>(gemm_splitk_workspace(d, d, (int)B, 1)));
@@ -987,18 +996,48 @@ int gtg_head_fwd_bwd(const float* h, const float* Wmu, const float* bmu, const f
     g = GemmDesc();
     g.A = y1; g.lda = hid; g.B = D2; g.ldb = hid; g.C = out; g.ldc = m_out;
     g.M = B; g.N = m_out; g.K = hid; g.bias = c2; g.epi = EPI_SIGMOID;
-    GTG_TRY(gemm(g, s));
-    GTG_TRY(bce_fwd(out, adj_target, B, n, w.bcep, nullptr, dlogits, gscale_dev, s));
+    // On a batch-sized product the loss is the epilogue of the decoder's last layer: the probabilities are stored
+    // and, from the registers that hold them, turned into loss terms and the gradient w.r.t. the logits -- element
+    // for element what bce_fwd_kernel computes; the loss itself is summed from per-wave instead of per-graph
+    // partials (the one output of this call that differs from the separate calls', in its last bits).
+    long long bce_parts = B;
+    if (gemm_fused_epilogue_ok(B, m_out, hid)) {
+        g.epi = EPI_SIGMOID_BCE;
+        g.fuse.bce_target = adj_target;
+        g.fuse.bce_n = n;
+        g.fuse.bce_gscale = 1.f / ((float)B * (float)m_out);
+        g.fuse.bce_gscale_dev = gscale_dev;
+        g.fuse.bce_dlogits = dlogits;
+        g.fuse.bce_partial = w.bcep;
+        bce_parts = gemm_bce_partials(B, m_out, hid);
+        GTG_TRY(gemm(g, s));
+    } else {
+        GTG_TRY(gemm(g, s));
+        GTG_TRY(bce_fwd(out, adj_target, B, n, w.bcep, nullptr, dlogits, gscale_dev, s));
+    }
 
     // ---- backward; the loss terms' final sums and Adam's step counter ride with its first launch
     SideJobs extra;
     bool ok = extra.add_sum(w.klp, reparam_kl_partials(B, d), reparam_kl_scale(B), kl);
-    ok = extra.add_sum(w.bcep, B, bce_scale(B, n), loss) && ok;
+    ok = extra.add_sum(w.bcep, bce_parts, bce_scale(B, n), loss) && ok;
     if (adam_state16 != nullptr) ok = extra.add_adam_prepare(adam_state16, lr, beta1, beta2) && ok;
     if (!ok) return set_error(GTG_ERR_LAUNCH, "gtg_head_fwd_bwd: side job list full");
-    GTG_TRY(decoder_bwd_launches(z, D1, D2, y1, dlogits, B, d, hid, m_out, dD1, dc1, dD2, dc2, dz, w.dec, &extra, s));
+    // the gradients w.r.t. mu and logvar as the epilogue of the product that writes dz, where that product is a
+    // batch-sized one (the same arithmetic as latent_bwd_kernel: bit-identical)
+    const bool stacked = (Wlv == Wmu + (size_t)d * d);
+    GemmFuse lat;
+    lat.mu = mu; lat.lv = logvar; lat.eps = eps;
+    lat.kl_w_dev = kl_w_dev; lat.kl_w = 1.f; lat.inv_b = 1.f / (float)B;
+    lat.dmu = w.dboth;
+    lat.dlv = stacked ? w.dboth + d : w.dboth + (size_t)B * d;
+    lat.ld_out = stacked ? 2 * d : d;
+    const bool fuse_lat = gemm_fused_epilogue_ok(B, d, hid) && d % 4 == 0 &&
+                          ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(logvar) |
+                            reinterpret_cast<uintptr_t>(eps) | reinterpret_cast<uintptr_t>(w.dboth)) & 15) == 0;
+    GTG_TRY(decoder_bwd_launches(z, D1, D2, y1, dlogits, B, d, hid, m_out, dD1, dc1, dD2, dc2, dz, w.dec, &extra,
+                                 fuse_lat ? &lat : nullptr, s));
     return latent_bwd_launches(h, Wmu, Wlv, mu, logvar, eps, dz, 1.f, kl_w_dev, B, d, dWmu, dbmu, dWlv, dblv, dh,
-                               w.dboth, w.cs, w.slabs, s);
+                               w.dboth, w.cs, w.slabs, s, fuse_lat);
 }
 
 // ---------------------------------------------------------------------------

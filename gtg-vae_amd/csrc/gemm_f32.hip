@@ -62,6 +62,7 @@ struct KArgs {
     // PREC 5 (fp16 plane images [2][K/16][rows][16]): inverse row scales of A (M) and of B (N)
     const float* inv_a_rows;
     const float* inv_b_rows;
+    GemmFuse fuse;  // EPI_SIGMOID_BCE / EPI_LATENT_BWD
 };
 
 constexpr int ABSMAX_PARTS = GEMM_ABSMAX_PARTS;
@@ -1215,11 +1216,14 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
             for (int e = 0; e < 16; ++e)
                 sC[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + 32 * j + r] = acc[i][j][e];
     __syncthreads();
-    if (KG > 1 && kg != 0) return;  // group 0 sums the groups' tiles below
 
     constexpr int LPR = WTN / 4;   // lanes per row
     constexpr int RPI = 64 / LPR;  // rows per wave instruction
     constexpr int NIT = WTM / RPI;
+    // K-group configurations: the groups' waves share the store loop (iteration `it` belongs to group it % KG),
+    // each summing every group's staged tile for its rows, in group order
+    constexpr int NOWN = (KG > 1) ? (NIT + KG - 1) / KG : NIT;
+    const float* const sR = smem + wave * (WTM * LDC);  // group 0's staged tile at this wave's position
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int gcol = n0 + wn + c4 * 4;
     const bool vec_ok = a.vecC && gcol + 3 < a.N;
@@ -1229,16 +1233,17 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         for (int q = 0; q < 4; ++q)
             if (gcol + q < a.N) bv[q] = bias[gcol + q];
     }
-    f32x4 xv[NIT];
+    f32x4 xv[NOWN];
     if (epi == EPI_MASK || epi == EPI_ACCUM) {
         const float* __restrict__ src = (epi == EPI_MASK) ? aux : C;
         const int lds = (epi == EPI_MASK) ? a.ldaux : ldc;
         const bool vsrc = (epi == EPI_MASK) ? (a.vecAux && gcol + 3 < a.N) : vec_ok;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int u = 0; u < NOWN; ++u) {
+            const int it = KG > 1 ? u * KG + kg : u;
             const int grow = m0 + wm + it * RPI + rsub;
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (grow < Mr && gcol < a.N) {
+            if (it < NIT && grow < Mr && gcol < a.N) {
                 const float* p = src + (long long)grow * lds + gcol;
                 if (vsrc) {
                     t = *reinterpret_cast<const f32x4*>(p);
@@ -1248,7 +1253,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
                         if (gcol + q < a.N) t[q] = p[q];
                 }
             }
-            xv[it] = t;
+            xv[u] = t;
         }
     }
     f32x4 ib = {1.f, 1.f, 1.f, 1.f};
@@ -1259,10 +1264,55 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
     }
     // PREC 5: the inverse scales of this lane's rows, all fetched before the store loop (inside it every row
     // would wait for its own load)
-    float ia[NIT];
+    float ia[NOWN];
     if constexpr (PREC == 5) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) ia[it] = a.inv_a_rows[max(min(m0 + wm + it * RPI + rsub, Mr - 1), 0)];
+        for (int u = 0; u < NOWN; ++u) ia[u] = a.inv_a_rows[max(min(m0 + wm + u * RPI + rsub, Mr - 1), 0)];  // KG == 1
+    }
+    // EPI_SIGMOID_BCE: where in a graph's (n, n) target the lane's four triangle elements lie (bce_fwd_kernel's
+    // inversion of k = i n - i(i-1)/2 + (j - i)), and the targets of all its rows, fetched before the store loop
+    // (both fused epilogues exist in the K-group configurations only: their batch-sized products are the ones
+    // that use them, and the large tiles' register budget has no room for the prefetched operands)
+    constexpr bool FUSE = (KG > 1 && PREC == 0);
+    constexpr int FN = FUSE ? NOWN : 1;
+    int tij[4] = {0, 0, 0, 0};
+    f32x4 tv[FN];
+    float bce_sum = 0.f, bce_g = 0.f;
+    if (FUSE && epi == EPI_SIGMOID_BCE) {
+        const int n = a.fuse.bce_n;
+        const float tn1 = (float)(2 * n + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = min(gcol + q, a.N - 1);
+            int i = (int)((tn1 - sqrtf(tn1 * tn1 - 8.f * (float)k)) * 0.5f);
+            i = max(0, min(i, n - 1));
+            if (i * n - (i * (i - 1)) / 2 > k) --i;
+            else if (i + 1 < n && (i + 1) * n - ((i + 1) * i) / 2 <= k) ++i;
+            tij[q] = i * n + i + (k - (i * n - (i * (i - 1)) / 2));
+        }
+#pragma unroll
+        for (int u = 0; u < FN; ++u) {
+            const int grow = max(min(m0 + wm + (u * KG + kg) * RPI + rsub, Mr - 1), 0);
+            const float* trow = a.fuse.bce_target + (long long)grow * (n * n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tv[u][q] = trow[tij[q]];
+        }
+        bce_g = a.fuse.bce_gscale;
+        if (a.fuse.bce_gscale_dev != nullptr) bce_g *= a.fuse.bce_gscale_dev[0];
+    }
+    // EPI_LATENT_BWD: mu, logvar and eps of the lane's elements, fetched before the store loop
+    f32x4 lmu[FN], llv[FN], lep[FN];
+    float lat_w = 0.f;
+    if (FUSE && epi == EPI_LATENT_BWD) {
+#pragma unroll
+        for (int u = 0; u < FN; ++u) {
+            const long long o = (long long)max(min(m0 + wm + (u * KG + kg) * RPI + rsub, Mr - 1), 0) * a.N +
+                                max(min(gcol, a.N - 4), 0);
+            lmu[u] = *reinterpret_cast<const f32x4*>(a.fuse.mu + o);
+            llv[u] = *reinterpret_cast<const f32x4*>(a.fuse.lv + o);
+            lep[u] = *reinterpret_cast<const f32x4*>(a.fuse.eps + o);
+        }
+        lat_w = (a.fuse.kl_w_dev ? a.fuse.kl_w_dev[0] * a.fuse.kl_w : a.fuse.kl_w) * a.fuse.inv_b;
     }
     f32x4 colacc = {0.f, 0.f, 0.f, 0.f};  // this lane's share of the column sums of the stored values
     // The store loop is instantiated once per epilogue and chosen by ONE switch: with the switch inside the
@@ -1270,25 +1320,27 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
     auto store_rows = [&](auto epi_tag) {
         constexpr int E = decltype(epi_tag)::value;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int u = 0; u < NOWN; ++u) {
+            const int it = KG > 1 ? u * KG + kg : u;
+            if (NIT % (KG > 1 ? KG : 1) != 0 && it >= NIT) continue;
             const int lrow = it * RPI + rsub;
             const int grow = m0 + wm + lrow;
-            f32x4 v = *reinterpret_cast<const f32x4*>(&sC[lrow * LDC + c4 * 4]);
+            f32x4 v = *reinterpret_cast<const f32x4*>(&sR[lrow * LDC + c4 * 4]);
 #pragma unroll
-            for (int g = 1; g < KG; ++g) v += *reinterpret_cast<const f32x4*>(&sC[g * GW * WTM * LDC + lrow * LDC + c4 * 4]);
+            for (int g = 1; g < KG; ++g) v += *reinterpret_cast<const f32x4*>(&sR[g * GW * WTM * LDC + lrow * LDC + c4 * 4]);
             if (grow >= Mr || gcol >= a.N) continue;
             if constexpr (PREC == 5) {
                 // undo the operands' row scales (powers of two: exact)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (v[q] * ia[it]) * ib[q];
+                for (int q = 0; q < 4; ++q) v[q] = (v[q] * ia[u]) * ib[q];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float y = v[q] + bv[q];
                 if constexpr (E == EPI_RELU) y = fmaxf(y, 0.f);
-                if constexpr (E == EPI_SIGMOID) y = 1.f / (1.f + expf(-y));
-                if constexpr (E == EPI_MASK) y = (xv[it][q] > 0.f) ? y : 0.f;
-                if constexpr (E == EPI_ACCUM) y += xv[it][q];
+                if constexpr (E == EPI_SIGMOID || (FUSE && E == EPI_SIGMOID_BCE)) y = 1.f / (1.f + expf(-y));
+                if constexpr (E == EPI_MASK) y = (xv[u][q] > 0.f) ? y : 0.f;
+                if constexpr (E == EPI_ACCUM) y += xv[u][q];
                 v[q] = y;
             }
             colacc += v;
@@ -1300,6 +1352,40 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
                 for (int q = 0; q < 4; ++q)
                     if (gcol + q < a.N) dst[q] = v[q];
             }
+            if constexpr (FUSE && E == EPI_SIGMOID_BCE) {
+                f32x4 dl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float pq = v[q], tq = tv[u][q];
+                    const float lp = fmaxf(logf(pq), -100.f);
+                    const float lq = fmaxf(logf(1.f - pq), -100.f);
+                    if (gcol + q < a.N) bce_sum += (tq - 1.f) * lq - tq * lp;
+                    const float qq = (1.f - pq) * pq;
+                    dl[q] = (bce_g * (pq - tq) / fmaxf(qq, 1e-12f)) * qq;
+                }
+                float* gd = a.fuse.bce_dlogits + (long long)grow * a.N + gcol;
+                if (vec_ok) {
+                    *reinterpret_cast<f32x4*>(gd) = dl;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (gcol + q < a.N) gd[q] = dl[q];
+                }
+            }
+            if constexpr (FUSE && E == EPI_LATENT_BWD) {
+                // (N is a multiple of 4 and the rows 16-byte aligned in this mode: gemm_plan checks)
+                f32x4 gm, gl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float pm, pl;
+                    latent_bwd_point(v[q], lmu[u][q], llv[u][q], lep[u][q], lat_w, pm, pl);
+                    gm[q] = pm;
+                    gl[q] = pl;
+                }
+                const long long o = (long long)grow * a.fuse.ld_out + gcol;
+                *reinterpret_cast<f32x4*>(a.fuse.dmu + o) = gm;
+                *reinterpret_cast<f32x4*>(a.fuse.dlv + o) = gl;
+            }
         }
     };
     switch (epi) {
@@ -1307,7 +1393,19 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         case EPI_SIGMOID: store_rows(std::integral_constant<int, EPI_SIGMOID>{}); break;
         case EPI_MASK: store_rows(std::integral_constant<int, EPI_MASK>{}); break;
         case EPI_ACCUM: store_rows(std::integral_constant<int, EPI_ACCUM>{}); break;
+        case EPI_SIGMOID_BCE:
+            if constexpr (FUSE) store_rows(std::integral_constant<int, EPI_SIGMOID_BCE>{});
+            break;
+        case EPI_LATENT_BWD:
+            if constexpr (FUSE) store_rows(std::integral_constant<int, EPI_LATENT_BWD>{});
+            break;
         default: store_rows(std::integral_constant<int, EPI_STORE>{}); break;
+    }
+    if (FUSE && epi == EPI_SIGMOID_BCE) {
+        // the wave's loss terms, lanes added in a fixed order; one slot per wave of every tile
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bce_sum += __shfl_xor(bce_sum, o);
+        if (lane == 0) a.fuse.bce_partial[(((long long)tm * a.tiles_n + tn) * GW + wave) * KG + kg] = bce_sum;
     }
     // Column sums of what this wave stored (its WTM rows x WTN columns), rows in a fixed order: a bias
     // gradient then needs no pass of its own over C, only the sum of these per-row-block partials.
@@ -1614,6 +1712,21 @@ int gemm_pick_splits(int M, int N, int K, int batch)
     return (K + kps - 1) / kps;
 }
 
+bool gemm_fused_epilogue_ok(int M, int N, int K)
+{
+    const TileCfg cfg = pick_cfg(M, N, K, 1, EPI_STORE);
+    return cfg == CFG_32_K4 || cfg == CFG_64_K2;
+}
+
+long long gemm_bce_partials(int M, int N, int K)
+{
+    const TileCfg cfg = pick_cfg(M, N, K, 1, EPI_SIGMOID_BCE);
+    int bm, bn;
+    cfg_dims(cfg, bm, bn);
+    const int waves = cfg == CFG_32_K4 ? 4 : 8;  // waves per tile: 1 x 4 K groups, or 4 x 2 (every wave stores rows)
+    return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * waves;
+}
+
 size_t gemm_splitk_workspace(int M, int N, int K, int batch)
 {
     const int s = gemm_pick_splits(M, N, K, batch);
@@ -1645,8 +1758,25 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
         return set_error(GTG_ERR_INVALID, "gemm: null output");
     }
     if (d.epi == EPI_MASK && !d.aux) return set_error(GTG_ERR_INVALID, "gemm: mask epilogue without aux");
+    if (d.epi == EPI_SIGMOID_BCE || d.epi == EPI_LATENT_BWD) {
+        if (d.batch != 1 || d.splits > 1 || d.m_dev != nullptr || d.k_dev != nullptr || d.batch_dim != nullptr ||
+            d.tail_ws != nullptr || d.planes)
+            return set_error(GTG_ERR_INVALID, "gemm: a fused loss epilogue needs batch 1, no split-K, static extents");
+        const GemmFuse& f = d.fuse;
+        if (d.epi == EPI_SIGMOID_BCE &&
+            (!f.bce_target || !f.bce_dlogits || !f.bce_partial || f.bce_n < 1 || d.N != f.bce_n * (f.bce_n + 1) / 2))
+            return set_error(GTG_ERR_INVALID, "gemm: BCE epilogue needs targets, outputs and N = n(n+1)/2");
+        if (d.epi == EPI_LATENT_BWD &&
+            (!f.mu || !f.lv || !f.eps || !f.dmu || !f.dlv || d.N % 4 != 0 || f.ld_out % 4 != 0 ||
+             ((reinterpret_cast<uintptr_t>(f.mu) | reinterpret_cast<uintptr_t>(f.lv) | reinterpret_cast<uintptr_t>(f.eps) |
+               reinterpret_cast<uintptr_t>(f.dmu) | reinterpret_cast<uintptr_t>(f.dlv)) & 15) != 0))
+            return set_error(GTG_ERR_INVALID, "gemm: latent-backward epilogue needs 16-byte aligned rows of a multiple of 4");
+    }
 
     TileCfg cfg = d.planes ? CFG_128 : pick_cfg(d.M, d.N, d.K, d.batch, d.epi);
+    if ((d.epi == EPI_SIGMOID_BCE || d.epi == EPI_LATENT_BWD) && cfg != CFG_32_K4 && cfg != CFG_64_K2)
+        return set_error(GTG_ERR_INVALID, "gemm: the fused loss epilogues exist for batch-sized products only "
+                                          "(gemm_fused_epilogue_ok)");
     // Large products on the bf16 pipes: a 256x128 tile shared by eight waves (one block per CU) moves a quarter
     // less operand data per multiply-add than the 128x128 tile, through global memory, the split arithmetic and
     // the LDS stores alike.  Taken when it still gives every CU at least two tiles; a caller that offers a tail
@@ -1676,6 +1806,7 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
     k.absmax = d.absmax_ws;
     k.inv_a_rows = d.planes ? d.planes_inv_a : nullptr;
     k.inv_b_rows = d.planes ? d.planes_inv_b : nullptr;
+    k.fuse = d.fuse;
     k.A = d.A;
     k.B = d.B;
     k.C = d.C;

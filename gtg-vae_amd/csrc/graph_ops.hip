@@ -390,8 +390,10 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
     const float w = (kl_w_dev ? kl_w_dev[0] * kl_w : kl_w) * inv_b;
     const float m = mu[i], l = lv[i], g = dz ? dz[i] : 0.f;
     const int64_t o = (i / d) * ld + (i % d);  // the outputs may be the two halves of (B, 2d) rows
-    dmu[o] = g + w * m;
-    dlv[o] = g * (0.5f * eps[i] * expf(0.5f * l)) + w * 0.5f * (expf(l) - 1.f);
+    float gm, gl;
+    latent_bwd_point(g, m, l, eps[i], w, gm, gl);
+    dmu[o] = gm;
+    dlv[o] = gl;
 }
 
 // ---------------------------------------------------------------------------

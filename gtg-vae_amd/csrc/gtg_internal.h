@@ -36,6 +36,34 @@ enum GemmEpilogue : int {
     EPI_MASK = 3,      // C = aux[m,n] > 0 ? acc : 0
     EPI_ACCUM = 4,     // C += acc
     EPI_POOL = 5,      // per batch: pool_val[b,n] = max_m (acc + bias[n]), pool_idx = argmax (lowest m on ties)
+    // EPI_SIGMOID followed, on the values just stored, by the un-masked upper-triangular BCE against
+    // fuse.bce_target (graph_ops.hip: bce_fwd_kernel, element for element the same arithmetic): the gradient
+    // w.r.t. the logits goes to fuse.bce_dlogits (row pitch N) and every wave that stores leaves the sum of its
+    // loss terms in fuse.bce_partial (gemm_bce_partials() floats, all of them written).  Row m is graph m, column
+    // k the k-th element of the triangle, N = n(n+1)/2.  Batch 1, no split-K, no device-side extents.
+    EPI_SIGMOID_BCE = 6,
+    // EPI_STORE of dz followed by the backward of the reparameterisation and the KL term (graph_ops.hip:
+    // latent_bwd_kernel, the same arithmetic): fuse.dmu / fuse.dlv receive the gradients w.r.t. mu and logvar at
+    // row pitch fuse.ld_out.  Batch 1, no split-K.
+    EPI_LATENT_BWD = 7,
+};
+
+// Operands of the fused epilogues EPI_SIGMOID_BCE and EPI_LATENT_BWD.
+struct GemmFuse {
+    const float* bce_target = nullptr;  // (M, n, n) padded targets
+    int bce_n = 0;
+    float bce_gscale = 0.f;             // 1 / (M N), times *bce_gscale_dev when given
+    const float* bce_gscale_dev = nullptr;
+    float* bce_dlogits = nullptr;       // (M, N)
+    float* bce_partial = nullptr;
+    const float* mu = nullptr;          // (M, N) each, row pitch N
+    const float* lv = nullptr;
+    const float* eps = nullptr;
+    const float* kl_w_dev = nullptr;    // optional device scalar multiplied into kl_w
+    float kl_w = 0.f, inv_b = 0.f;
+    float* dmu = nullptr;
+    float* dlv = nullptr;
+    int ld_out = 0;
 };
 
 struct GemmDesc {
@@ -104,7 +132,12 @@ struct GemmDesc {
     // extra blocks of its launch when the launch is one of the K-group configurations (batch-sized products) and
     // run as a launch of their own in front of it otherwise.  gemm_pair takes those of its first product.
     const SideJobs* side = nullptr;
+    GemmFuse fuse;  // EPI_SIGMOID_BCE / EPI_LATENT_BWD
 };
+// Number of loss partials an EPI_SIGMOID_BCE product of this shape writes (one per storing wave).
+long long gemm_bce_partials(int M, int N, int K);
+// Whether a product of this shape (batch 1) runs a configuration that has the fused epilogues.
+bool gemm_fused_epilogue_ok(int M, int N, int K);
 constexpr int GEMM_ABSMAX_PARTS = 1024;
 constexpr size_t GEMM_ABSMAX_BYTES = 2 * GEMM_ABSMAX_PARTS * sizeof(float);
 // GEMM_ABSMAX_PARTS partial maxima of |x| over a (rows, cols) fp32 array with leading dimension ld, written to
@@ -129,6 +162,17 @@ __device__ __forceinline__ void f16x2_scale(float mx, float& scale, float& inver
 // w1 -- the same values as scaling, converting, converting back, subtracting and converting again, which
 // the compiler builds from seven instructions per pair (it converts the first plane twice, once packed for
 // the store and once per element as the subtrahend).
+// Backward of z = eps exp(logvar / 2) + mu and of the KL term at one element: g = dL/dz, w = KL weight / B.
+// Written with explicit fused multiply-adds so that the stand-alone kernel (graph_ops.hip) and the GEMM epilogue
+// that computes the same thing (gemm_f32.hip, EPI_LATENT_BWD) round identically: left to the compiler, a sum of
+// two products is contracted around either one.
+__device__ __forceinline__ void latent_bwd_point(float g, float m, float l, float e, float w, float& gm, float& gl)
+{
+    gm = __fmaf_rn(w, m, g);
+    const float t1 = __fmul_rn(__fmul_rn(0.5f, e), expf(__fmul_rn(0.5f, l)));
+    const float t2 = __fmul_rn(__fmul_rn(w, 0.5f), __fsub_rn(expf(l), 1.f));
+    gl = __fmaf_rn(g, t1, t2);
+}
 __device__ __forceinline__ void split_pair_f16(float x0, float x1, float scale, unsigned& w0, unsigned& w1)
 {
     unsigned a, b;

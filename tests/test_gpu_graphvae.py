@@ -296,7 +296,9 @@ def test_bce_clamp_at_the_ends(golden_dir):
 def test_fused_head_equals_the_five_calls_bit_for_bit(B, N, d, hid, adam):
     """gtg_head_fwd_bwd (latent head + decoder + loss, forward and backward, the scalars' final sums and Adam's
     step counter riding in spare blocks of a later launch) against gtg_latent_fwd, gtg_decoder_fwd,
-    gtg_bce_loss_fwd, gtg_decoder_bwd, gtg_latent_bwd and gtg_adam_step's counter: every output bit-identical.
+    gtg_bce_loss_fwd, gtg_decoder_bwd, gtg_latent_bwd and gtg_adam_step's counter: every output bit-identical
+    except the reconstruction loss scalar (the loss terms and their gradient are computed in the epilogue of the
+    decoder's last product and summed in another order).
     (The five calls are themselves checked against the oracle and the reference's goldens above and below.)
     1100 graphs: more rows than a riding column sum takes, the stand-alone launches run instead."""
     from gtg_vae_amd import _lib
@@ -358,9 +360,15 @@ def test_fused_head_equals_the_five_calls_bit_for_bit(B, N, d, hid, adam):
         torch.cuda.synchronize()
         for k in a:
             assert not torch.isnan(b[k]).any(), k
+            if k == "sc":
+                # the KL term is the same sum; the reconstruction loss is summed from per-wave partials of the
+                # decoder's last product instead of per-graph ones: same terms, another order of additions
+                assert a[k][1].item() == b[k][1].item()
+                assert b[k][0].item() == pytest.approx(a[k][0].item(), rel=2e-6)
+                continue
             assert torch.equal(a[k], b[k]), (rep, k, (a[k] - b[k]).abs().max().item())
         if 256 <= B <= 1024:      # batch sizes whose weight-gradient launches carry the side jobs
-            assert launches <= 10, launches
+            assert launches <= 8, launches
 
 
 @pytest.mark.parametrize("B,N,d,hid", CONFIGS)
