@@ -622,14 +622,23 @@ int gtg_encoder_compact_bwd(const float* adj, const float* adjc, const int32_t* 
     const bool fused_db1 = gemm_colsum_rows(rows) <= 1024 && B <= 1024 && (long long)((rows + 127) / 128) * ((H + 127) / 128) >= 192;
     if (fused_db1) g.colsum_part = w.cs;
     GTG_TRY(gemm(g, s));
-    if (fused_db1)
+    // (where the sparse dW1 path follows, the two column sums ride in the front blocks of its reduce launch: they
+    // are final here and nothing before that launch's end needs them)
+    SideJobs bias_sums;
+    const bool riding = fused_db1 && dw1_sp &&
+                        bias_sums.add_colsum(w.cs, gemm_colsum_rows(rows), H, H, db1, all_rows, 128, 2) &&
+                        bias_sums.add_colsum(dpooled, B, d, d, db2);
+    if (riding) {
+    } else if (fused_db1) {
         GTG_TRY(colsum_parts_and_short(w.cs, gemm_colsum_rows(rows), all_rows, H, db1, dpooled, B, d, d, db2, nullptr, s));
-    else
+    } else {
         GTG_TRY(colsum_dev_and_short(w.dZ1c, rows, all_rows, H, H, w.cs, db1, dpooled, B, d, d, db2, s));
+    }
     // dW1[c][i] = sum over stored rows dZ1c[r][c] * adjc[r][i]   (prototype rows carry unit adjacency rows):
     // through the nonzeros of the adjacency rows where the shape allows, else as the dense product
     if (dw1_sp)
-        return dw1_sparse(adjc, n, w.dZ1c, H, all_rows, rows, w.dw1, dW1, dw2_deferred ? w.dw2 : nullptr, d, dW2, s);
+        return dw1_sparse(adjc, n, w.dZ1c, H, all_rows, rows, w.dw1, dW1, dw2_deferred ? w.dw2 : nullptr, d, dW2, s,
+                          riding ? &bias_sums : nullptr);
     g = GemmDesc();
     g.A = w.dZ1c; g.lda = H; g.a_kc = false;
     g.B = adjc; g.ldb = n; g.b_kc = false;

@@ -579,10 +579,20 @@ __global__ __launch_bounds__(256) void dw_reduce_pair_kernel(const DwReduceJob j
 // per lane, added in group order as above (bit-identical results).
 constexpr int RV_C = 64, RV_H = 16;
 
-__global__ __launch_bounds__(256) void dw_reduce_pair_vec_kernel(const DwReduceJob j0, const DwReduceJob j1)
+// The first sj.blocks() blocks of the launch run side jobs (side_jobs.h): the encoder's bias gradients, column sums
+// that are final before this launch and that nothing in it reads.
+__global__ __launch_bounds__(256) void dw_reduce_pair_vec_kernel(const DwReduceJob j0, const DwReduceJob j1,
+                                                                 const SideJobs sj)
 {
-    __shared__ float tile[RV_H][RV_C + 1];
-    int b = blockIdx.x;
+    static_assert(SIDE_SMEM_FLOATS >= RV_H * (RV_C + 1), "the transposition tile lives in the side jobs' LDS");
+    __shared__ __attribute__((aligned(16))) float smem[SIDE_SMEM_FLOATS];
+    float (*const tile)[RV_C + 1] = reinterpret_cast<float (*)[RV_C + 1]>(smem);
+    const int ns = sj.first_block[SIDE_MAX_JOBS];
+    if ((int)blockIdx.x < ns) {  // block-uniform
+        side_run<256>(sj, (int)blockIdx.x, smem);
+        return;
+    }
+    int b = (int)blockIdx.x - ns;
     const bool first = b < j0.blocks;  // block-uniform
     if (!first) b -= j0.blocks;
     const float* __restrict__ partial = first ? j0.partial : j1.partial;
@@ -627,8 +637,12 @@ inline DwReduceJob dw_reduce_job(const float* partial, int d, int H, float* out,
     return j;
 }
 
-int dw_reduce_pair(const DwReduceJob& j0, const DwReduceJob& j1, hipStream_t s)
+// `side` (nullable): side jobs that ride in front of the reduction's blocks (a launch of their own where the
+// reduction runs the scalar kernel).
+int dw_reduce_pair(const DwReduceJob& j0, const DwReduceJob& j1, hipStream_t s, const SideJobs* side = nullptr)
 {
+    SideJobs sj;
+    if (side != nullptr) sj = *side;
     auto vec_ok = [](const DwReduceJob& j) {
         return j.blocks == 0 || (j.d % 4 == 0 && j.d >= 4 && j.H % RV_H == 0 && (reinterpret_cast<uintptr_t>(j.partial) & 15) == 0);
     };
@@ -639,9 +653,11 @@ int dw_reduce_pair(const DwReduceJob& j0, const DwReduceJob& j1, hipStream_t s)
             j->bx = (j->d + RV_C - 1) / RV_C;
             j->blocks = j->bx * (j->H / RV_H);
         }
-        hipLaunchKernelGGL(dw_reduce_pair_vec_kernel, dim3(a.blocks + b.blocks), dim3(256), 0, s, a, b);
+        hipLaunchKernelGGL(dw_reduce_pair_vec_kernel, dim3(a.blocks + b.blocks + sj.blocks()), dim3(256), 0, s, a, b, sj);
         return check_launch("dw_reduce_pair_vec_kernel");
     }
+    if (sj.blocks() > 0)
+        if (int rc = side_jobs_launch(sj, s)) return rc;
     hipLaunchKernelGGL(dw_reduce_pair_kernel, dim3(j0.blocks + j1.blocks), dim3(256), 0, s, j0, j1);
     return check_launch("dw_reduce_pair_kernel");
 }
@@ -867,7 +883,7 @@ bool dw1_sparse_applies(int64_t rows, int n, int H)
 size_t dw1_sparse_workspace(int H) { return (size_t)D1_CHUNKS * 64 * H * sizeof(float); }
 
 int dw1_sparse(const float* adjc, int n, const float* dZ1c, int H, const int* rows_dev, int64_t rows_max, float* partial,
-               float* dW1, const float* dw2_partial, int d, float* dW2, hipStream_t s)
+               float* dW1, const float* dw2_partial, int d, float* dW2, hipStream_t s, const SideJobs* side)
 {
     if (!dw1_sparse_applies(rows_max, n, H)) return set_error(GTG_ERR_INVALID, "dw1_sparse: shape not supported");
     ProfScope prof(s, "dw1_sparse", rows_max, H, n);
@@ -884,7 +900,7 @@ int dw1_sparse(const float* adjc, int n, const float* dZ1c, int H, const int* ro
     // partial[chunk][i][c] -> dW1[c][i]; the deferred reduction of dW2's partials rides in the same launch
     DwReduceJob j2 = dw_reduce_job(dw2_partial, d, H, dW2, H, H);
     if (dw2_partial == nullptr) j2.blocks = 0;
-    return dw_reduce_pair(j2, dw_reduce_job(partial, H, 64, dW1, n, n), s);
+    return dw_reduce_pair(j2, dw_reduce_job(partial, H, 64, dW1, n, n), s, side);
 }
 
 }  // namespace gtg

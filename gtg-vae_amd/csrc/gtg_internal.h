@@ -325,7 +325,7 @@ size_t dw1_sparse_workspace(int H);
 // dw2_partial (nullable): partials of a dw2_sparse call made with defer_reduce, reduced into dW2 (d x H) by the
 // launch that reduces dW1's.
 int dw1_sparse(const float* adjc, int n, const float* dZ1c, int H, const int* rows_dev, int64_t rows_max, float* partial,
-               float* dW1, const float* dw2_partial, int d, float* dW2, hipStream_t s);
+               float* dW1, const float* dw2_partial, int d, float* dW2, hipStream_t s, const SideJobs* side = nullptr);
 int pool_sparse(const float* adj, const float* t2c, const int32_t* meta, const float* b2, int64_t B, int n, int d,
                 float* pooled, int32_t* argmax, hipStream_t s);
 

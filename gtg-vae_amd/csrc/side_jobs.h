@@ -25,6 +25,8 @@ struct AdamState {
 struct SideJob {
     int kind;
     int rows, cols, ld, vec;  // SIDE_COLSUM: X is rows x cols with row pitch ld; vec: 16-byte loads allowed
+    const int* rows_dev;      // SIDE_COLSUM, optional: rows = min(rows, mult * ceil(*rows_dev / unit))
+    int unit, mult;
     const float* x;           // SIDE_COLSUM: X; SIDE_SUM: the addends
     float* out;               // SIDE_ADAM_PREPARE: the AdamState
     long long n;              // SIDE_SUM: number of addends
@@ -45,9 +47,12 @@ struct SideJobs {
     int blocks() const { return first_block[count]; }
     bool full() const { return count >= SIDE_MAX_JOBS; }
     // each returns false when the job cannot ride (the caller then runs the stand-alone kernel)
-    bool add_colsum(const float* X, long long rows, int cols, int ld, float* out)
+    // rows_dev (optional, device scalar): only min(rows, mult * ceil(*rows_dev / unit)) rows are valid -- the
+    // per-row-block column sums a GEMM with a device-side row count leaves (two per live 128-row tile)
+    bool add_colsum(const float* X, long long rows, int cols, int ld, float* out, const int* rows_dev = nullptr,
+                    int unit = 1, int mult = 1)
     {
-        if (full() || rows < 1 || rows > SIDE_MAX_ROWS || cols < 1) return false;
+        if (full() || rows < 1 || rows > SIDE_MAX_ROWS || cols < 1 || unit < 1) return false;
         SideJob& j = job[count];
         j = SideJob();
         j.kind = SIDE_COLSUM;
@@ -57,6 +62,9 @@ struct SideJobs {
         j.cols = cols;
         j.ld = ld;
         j.vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ld % 4 == 0);
+        j.rows_dev = rows_dev;
+        j.unit = unit;
+        j.mult = mult;
         push((cols + SIDE_COLS - 1) / SIDE_COLS);
         return true;
     }
@@ -120,21 +128,31 @@ __device__ __forceinline__ void side_run(const SideJobs& sj, const int block, fl
         f32x4 s[PASSES];
 #pragma unroll
         for (int u = 0; u < PASSES; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int rows = j.rows;
+        if (j.rows_dev != nullptr) rows = min(rows, j.mult * ((j.rows_dev[0] + j.unit - 1) / j.unit));
         if (col < j.cols) {
             if (j.vec && col + 3 < j.cols) {
-                for (int r0 = 0; r0 < j.rows; r0 += 64) {
+                // whole groups of 64 rows without a guard, several groups' loads in flight per thread (a guarded
+                // load waits for its predecessor); the additions into each row lane keep their order
+                const float* x = j.x + (long long)rl * j.ld + col;
+                int r0 = 0;
+#pragma unroll 4
+                for (; r0 + 64 <= rows; r0 += 64) {
 #pragma unroll
-                    for (int u = 0; u < PASSES; ++u) {
-                        const int r = r0 + u * RL + rl;
-                        if (r < j.rows) s[u] += *reinterpret_cast<const f32x4*>(j.x + (long long)r * j.ld + col);
-                    }
+                    for (int u = 0; u < PASSES; ++u)
+                        s[u] += *reinterpret_cast<const f32x4*>(x + (long long)(r0 + u * RL) * j.ld);
+                }
+#pragma unroll
+                for (int u = 0; u < PASSES; ++u) {
+                    const int r = r0 + u * RL + rl;
+                    if (r < rows) s[u] += *reinterpret_cast<const f32x4*>(j.x + (long long)r * j.ld + col);
                 }
             } else {
-                for (int r0 = 0; r0 < j.rows; r0 += 64) {
+                for (int r0 = 0; r0 < rows; r0 += 64) {
 #pragma unroll
                     for (int u = 0; u < PASSES; ++u) {
                         const int r = r0 + u * RL + rl;
-                        if (r < j.rows) {
+                        if (r < rows) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
                                 if (col + q < j.cols) s[u][q] += j.x[(long long)r * j.ld + col + q];
