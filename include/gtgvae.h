@@ -247,9 +247,15 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
  * (loss.backward(), src/train.py:313).  Outputs are bit-identical to
  * gtg_latent_fwd, gtg_decoder_fwd, gtg_bce_loss_fwd(dlogits), gtg_decoder_bwd
  * (dout = dlogits, out = NULL) and gtg_latent_bwd(kl_w = 1, kl_w_dev) run in
- * that order; it exists because a call of its own must finish its scalars
- * inside its own launches, while here the final sums of `loss` and `kl` ride in
- * spare blocks of a later launch (three kernel boundaries fewer per step).
+ * that order, with one exception: at batch sizes whose decoder products run
+ * the small-tile configurations (up to about 1500 graphs at n = 64) the
+ * scalar `loss` is the sum of the same terms in another order and may differ
+ * in its last bits.  The call exists because a call of its own must finish
+ * inside its own launches: here the final sums of `loss` and `kl` ride in
+ * spare blocks of a later launch, the loss terms and dlogits are computed in
+ * the epilogue of the decoder's last product (the probabilities are never read
+ * back) and the gradients w.r.t. mu / logvar in the epilogue of the product
+ * that yields dz (seven kernel boundaries fewer per step than the five calls).
  *   h (B, d) pooled encoder output; eps (B, d); adj_target (B, n, n);
  *   kl_w_dev: device scalar, weight of the KL term in the backward (NULL = 1);
  *   gscale_dev: device scalar multiplied into dlogits (NULL = 1), as in
