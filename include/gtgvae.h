@@ -255,7 +255,8 @@ int gtg_decoder_bwd(const float* z, const float* D1, const float* D2, const floa
  * spare blocks of a later launch, the loss terms and dlogits are computed in
  * the epilogue of the decoder's last product (the probabilities are never read
  * back) and the gradients w.r.t. mu / logvar in the epilogue of the product
- * that yields dz (seven kernel boundaries fewer per step than the five calls).
+ * that yields dz (seven launches where the five calls and the counter kernel of
+ * gtg_adam_step take twelve).
  *   h (B, d) pooled encoder output; eps (B, d); adj_target (B, n, n);
  *   kl_w_dev: device scalar, weight of the KL term in the backward (NULL = 1);
  *   gscale_dev: device scalar multiplied into dlogits (NULL = 1), as in
