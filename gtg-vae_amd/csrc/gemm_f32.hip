@@ -460,7 +460,7 @@ struct TileB {
 template <int BM, int BN, int NPL = 3>
 struct PlaneStage {
     static constexpr int KS = 16;
-    static constexpr int STAGES = NPL == 2 ? 4 : 3;             // the two-plane stages are smaller: one more fits
+    static constexpr int STAGES = 3;
     static constexpr int ROWB = 2 * KS;                         // bytes per row per plane
     static constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
     static constexpr int STAGE_BYTES = NPL * (PLANE_A + PLANE_B);
@@ -493,6 +493,13 @@ __device__ __forceinline__ f32x16 mfma_16bit(bf16x8 x, bf16x8 y, f32x16 c)
 // Operand buffers per wave group: two (the next tile is staged while the current one is multiplied), except where
 // a K group is a single wave -- its buffer is private to the wave, LDS executes a wave's accesses in order, so
 // one buffer needs no barrier at all and half the LDS lets twice as many blocks share a CU.
+// The fp16-plane kernel stages its accumulators for the epilogue in two halves (half the staging area).
+template <int KG, int PREC>
+constexpr bool gemm_epilogue_halves()
+{
+    return KG == 1 && PREC == 5;
+}
+
 template <int WAVES_M, int WAVES_N, int KG, int PREC>
 constexpr int gemm_group_buffers()
 {
@@ -504,7 +511,7 @@ constexpr int gemm_group_buffers()
 template <int WAVES_M, int WAVES_N, int KG, int PREC>
 constexpr int gemm_min_waves()
 {
-    return (PREC == 0 && KG > 1 && WAVES_M * WAVES_N == 1) ? 4 : 1;
+    return (PREC == 0 && KG > 1 && WAVES_M * WAVES_N == 1) ? 4 : (PREC == 5 ? 3 : 1);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KG, bool AKC, bool BKC, int PREC>
@@ -519,7 +526,7 @@ constexpr int gemm_smem_floats()
     constexpr int MAIN = (PREC == 4)   ? PlaneStage<BM, BN, 3>::STAGES * PlaneStage<BM, BN, 3>::STAGE_BYTES / 4
                          : (PREC == 5) ? PlaneStage<BM, BN, 2>::STAGES * PlaneStage<BM, BN, 2>::STAGE_BYTES / 4
                                        : KG * gemm_group_buffers<WAVES_M, WAVES_N, KG, PREC>() * (TA::SIZE + TB::SIZE),
-                  EPI = KG * WAVES_M * WAVES_N * WTM * (WTN + 4);
+                  EPI = KG * WAVES_M * WAVES_N * (WTM / (gemm_epilogue_halves<KG, PREC>() && WTM == 64 ? 2 : 1)) * (WTN + 4);
     // + 4: the tail split's "last arriver" word lives behind the buffers, in the same array (a second __shared__
     // object beside an array that LDS-DMA fills makes the compiler drain all loads before every LDS read).  The
     // two-plane fp16 tiles (k step 32) fill exactly half a CU's LDS with the 128x128 tile's four buffers, and the
@@ -1259,6 +1266,15 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
     const int epi = a.to_slabs ? (int)EPI_STORE : a.epi;
     const float* __restrict__ bias = (a.to_slabs || a.bias == nullptr) ? nullptr : a.bias + batch * a.strideBias;
 
+    constexpr int LPR = WTN / 4;   // lanes per row
+    constexpr int RPI = 64 / LPR;  // rows per wave instruction
+    constexpr int NIT = WTM / RPI;
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int gcol = n0 + wn + c4 * 4;
+    const bool vec_ok = a.vecC && gcol + 3 < a.N;
+    f32x4 colacc = {0.f, 0.f, 0.f, 0.f};  // this lane's share of the column sums of the stored values
+    constexpr bool HALVES = gemm_epilogue_halves<KG, PREC>() && TM == 2;
+    if constexpr (!HALVES) {
     // Stage the wave's WTM x WTN accumulator tile through LDS (the operand
     // buffers are free after the last barrier of the main loop) so that global
     // stores -- and the aux / C loads of the mask and accumulate epilogues --
@@ -1274,16 +1290,10 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
                 sC[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + 32 * j + r] = acc[i][j][e];
     __syncthreads();
 
-    constexpr int LPR = WTN / 4;   // lanes per row
-    constexpr int RPI = 64 / LPR;  // rows per wave instruction
-    constexpr int NIT = WTM / RPI;
     // K-group configurations: the groups' waves share the store loop (iteration `it` belongs to group it % KG),
     // each summing every group's staged tile for its rows, in group order
     constexpr int NOWN = (KG > 1) ? (NIT + KG - 1) / KG : NIT;
     const float* const sR = smem + wave * (WTM * LDC);  // group 0's staged tile at this wave's position
-    const int c4 = lane % LPR, rsub = lane / LPR;
-    const int gcol = n0 + wn + c4 * 4;
-    const bool vec_ok = a.vecC && gcol + 3 < a.N;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias != nullptr) {
 #pragma unroll
@@ -1371,7 +1381,6 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         }
         lat_w = (a.fuse.kl_w_dev ? a.fuse.kl_w_dev[0] * a.fuse.kl_w : a.fuse.kl_w) * a.fuse.inv_b;
     }
-    f32x4 colacc = {0.f, 0.f, 0.f, 0.f};  // this lane's share of the column sums of the stored values
     // The store loop is instantiated once per epilogue and chosen by ONE switch: with the switch inside the
     // loop the compiler keeps it there, a chain of scalar compares and branches per element.
     auto store_rows = [&](auto epi_tag) {
@@ -1463,6 +1472,225 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) bce_sum += __shfl_xor(bce_sum, o);
         if (lane == 0) a.fuse.bce_partial[(((long long)tm * a.tiles_n + tn) * GW + wave) * KG + kg] = bce_sum;
+    }
+    } else {
+    // Stage the wave's WTM x WTN accumulator tile through LDS (the operand
+    // buffers are free after the last barrier of the main loop) so that global
+    // stores -- and the aux / C loads of the mask and accumulate epilogues --
+    // are whole 16-byte row segments, 4 or 8 full rows per wave instruction,
+    // instead of one dword per lane per accumulator register.
+    // The fp16-plane kernel stages and stores its tile in two halves of 32 rows (HALVES): a wave's staging area
+    // is its own (LDS executes a wave's accesses in order, so the second half is written over the first with no
+    // barrier), and half the staging area is what lets a third block share a CU's LDS.
+    constexpr int NH = HALVES ? 2 : 1;
+    constexpr int HROWS = WTM / NH;  // rows staged at a time
+    constexpr int NIT_H = NIT / NH;  // store-loop iterations per staged part
+    // K-group configurations: the groups' waves share the store loop (iteration `it` belongs to group it % KG),
+    // each summing every group's staged tile for its rows, in group order
+    constexpr int NOWN = (KG > 1) ? (NIT + KG - 1) / KG : NIT_H;
+    static_assert(!HALVES || (KG == 1 && NIT % 2 == 0), "staging in halves is written for one wave group");
+    float* const sC = smem + (kg * GW + wave) * (HROWS * LDC);
+    const float* const sR = smem + wave * (HROWS * LDC);  // group 0's staged tile at this wave's position
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ib = {1.f, 1.f, 1.f, 1.f};
+    // EPI_SIGMOID_BCE: where in a graph's (n, n) target the lane's four triangle elements lie (bce_fwd_kernel's
+    // inversion of k = i n - i(i-1)/2 + (j - i)), and the targets of all its rows, fetched before the store loop
+    // (both fused epilogues exist in the K-group configurations only: their batch-sized products are the ones
+    // that use them, and the large tiles' register budget has no room for the prefetched operands)
+    constexpr bool FUSE = (KG > 1 && PREC == 0);
+    constexpr int FN = FUSE ? NOWN : 1;
+    int tij[4] = {0, 0, 0, 0};
+    f32x4 tv[FN];
+    float bce_sum = 0.f, bce_g = 0.f;
+    // EPI_LATENT_BWD: mu, logvar and eps of the lane's elements, fetched before the store loop
+    f32x4 lmu[FN], llv[FN], lep[FN];
+    float lat_w = 0.f;
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+        // this part's accumulators into the staging area: all TM row tiles at once, or row tile hf
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (HALVES && i != hf) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    sC[((HALVES ? 0 : 32 * i) + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + 32 * j + r] = acc[i][j][e];
+        }
+        if constexpr (!HALVES) __syncthreads();  // (halves: the wave reads back only what it staged itself)
+        const int it0 = hf * NIT_H;  // first store-loop iteration of this part
+        if (hf == 0) {
+            // what every part of the store loop needs from global memory, requested once (after the first staging:
+            // placed in front of it, the same loads made the in-loop-split kernels' epilogue slower)
+            if (bias != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (gcol + q < a.N) bv[q] = bias[gcol + q];
+            }
+            if constexpr (PREC == 5) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (gcol + q < a.N) ib[q] = a.inv_b_rows[gcol + q];
+            }
+            if (FUSE && epi == EPI_SIGMOID_BCE) {
+                const int n = a.fuse.bce_n;
+                const float tn1 = (float)(2 * n + 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = min(gcol + q, a.N - 1);
+                    int i = (int)((tn1 - sqrtf(tn1 * tn1 - 8.f * (float)k)) * 0.5f);
+                    i = max(0, min(i, n - 1));
+                    if (i * n - (i * (i - 1)) / 2 > k) --i;
+                    else if (i + 1 < n && (i + 1) * n - ((i + 1) * i) / 2 <= k) ++i;
+                    tij[q] = i * n + i + (k - (i * n - (i * (i - 1)) / 2));
+                }
+#pragma unroll
+                for (int u = 0; u < FN; ++u) {
+                    const int grow = max(min(m0 + wm + (u * KG + kg) * RPI + rsub, Mr - 1), 0);
+                    const float* trow = a.fuse.bce_target + (long long)grow * (n * n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tv[u][q] = trow[tij[q]];
+                }
+                bce_g = a.fuse.bce_gscale;
+                if (a.fuse.bce_gscale_dev != nullptr) bce_g *= a.fuse.bce_gscale_dev[0];
+            }
+            if (FUSE && epi == EPI_LATENT_BWD) {
+#pragma unroll
+                for (int u = 0; u < FN; ++u) {
+                    const long long o = (long long)max(min(m0 + wm + (u * KG + kg) * RPI + rsub, Mr - 1), 0) * a.N +
+                                        max(min(gcol, a.N - 4), 0);
+                    lmu[u] = *reinterpret_cast<const f32x4*>(a.fuse.mu + o);
+                    llv[u] = *reinterpret_cast<const f32x4*>(a.fuse.lv + o);
+                    lep[u] = *reinterpret_cast<const f32x4*>(a.fuse.eps + o);
+                }
+                lat_w = (a.fuse.kl_w_dev ? a.fuse.kl_w_dev[0] * a.fuse.kl_w : a.fuse.kl_w) * a.fuse.inv_b;
+            }
+        }
+        f32x4 xv[NOWN];
+        if (epi == EPI_MASK || epi == EPI_ACCUM) {
+            const float* __restrict__ src = (epi == EPI_MASK) ? aux : C;
+            const int lds = (epi == EPI_MASK) ? a.ldaux : ldc;
+            const bool vsrc = (epi == EPI_MASK) ? (a.vecAux && gcol + 3 < a.N) : vec_ok;
+#pragma unroll
+            for (int u = 0; u < NOWN; ++u) {
+                const int it = KG > 1 ? u * KG + kg : it0 + u;
+                const int grow = m0 + wm + it * RPI + rsub;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (it < NIT && grow < Mr && gcol < a.N) {
+                    const float* p = src + (long long)grow * lds + gcol;
+                    if (vsrc) {
+                        t = *reinterpret_cast<const f32x4*>(p);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (gcol + q < a.N) t[q] = p[q];
+                    }
+                }
+                xv[u] = t;
+            }
+        }
+        // PREC 5: the inverse scales of this lane's rows, all fetched before the store loop (inside it every row
+        // would wait for its own load)
+        float ia[NOWN];
+        if constexpr (PREC == 5) {
+#pragma unroll
+            for (int u = 0; u < NOWN; ++u)
+                ia[u] = a.inv_a_rows[max(min(m0 + wm + (it0 + u) * RPI + rsub, Mr - 1), 0)];  // KG == 1
+        }
+        // The store loop is instantiated once per epilogue and chosen by ONE switch: with the switch inside the
+        // loop the compiler keeps it there, a chain of scalar compares and branches per element.
+        auto store_rows = [&](auto epi_tag) {
+            constexpr int E = decltype(epi_tag)::value;
+#pragma unroll
+            for (int u = 0; u < NOWN; ++u) {
+                const int it = KG > 1 ? u * KG + kg : it0 + u;
+                if (NIT % (KG > 1 ? KG : 1) != 0 && it >= NIT) continue;
+                const int lrow = it * RPI + rsub;       // row of the wave's tile
+                const int srow = lrow - hf * HROWS * (HALVES ? 1 : 0);  // row of the staging area
+                const int grow = m0 + wm + lrow;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&sR[srow * LDC + c4 * 4]);
+#pragma unroll
+                for (int g = 1; g < KG; ++g) v += *reinterpret_cast<const f32x4*>(&sR[g * GW * WTM * LDC + srow * LDC + c4 * 4]);
+                if (grow >= Mr || gcol >= a.N) continue;
+                if constexpr (PREC == 5) {
+                    // undo the operands' row scales (powers of two: exact)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (v[q] * ia[u]) * ib[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float y = v[q] + bv[q];
+                    if constexpr (E == EPI_RELU) y = fmaxf(y, 0.f);
+                    if constexpr (E == EPI_SIGMOID || (FUSE && E == EPI_SIGMOID_BCE)) y = 1.f / (1.f + expf(-y));
+                    if constexpr (E == EPI_MASK) y = (xv[u][q] > 0.f) ? y : 0.f;
+                    if constexpr (E == EPI_ACCUM) y += xv[u][q];
+                    v[q] = y;
+                }
+                colacc += v;
+                float* dst = C + (long long)grow * ldc + gcol;
+                if (vec_ok) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (gcol + q < a.N) dst[q] = v[q];
+                }
+                if constexpr (FUSE && E == EPI_SIGMOID_BCE) {
+                    f32x4 dl;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float pq = v[q], tq = tv[u][q];
+                        const float lp = fmaxf(logf(pq), -100.f);
+                        const float lq = fmaxf(logf(1.f - pq), -100.f);
+                        if (gcol + q < a.N) bce_sum += (tq - 1.f) * lq - tq * lp;
+                        const float qq = (1.f - pq) * pq;
+                        dl[q] = (bce_g * (pq - tq) / fmaxf(qq, 1e-12f)) * qq;
+                    }
+                    float* gd = a.fuse.bce_dlogits + (long long)grow * a.N + gcol;
+                    if (vec_ok) {
+                        *reinterpret_cast<f32x4*>(gd) = dl;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (gcol + q < a.N) gd[q] = dl[q];
+                    }
+                }
+                if constexpr (FUSE && E == EPI_LATENT_BWD) {
+                    // (N is a multiple of 4 and the rows 16-byte aligned in this mode: gemm_plan checks)
+                    f32x4 gm, gl;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float pm, pl;
+                        latent_bwd_point(v[q], lmu[u][q], llv[u][q], lep[u][q], lat_w, pm, pl);
+                        gm[q] = pm;
+                        gl[q] = pl;
+                    }
+                    const long long o = (long long)grow * a.fuse.ld_out + gcol;
+                    *reinterpret_cast<f32x4*>(a.fuse.dmu + o) = gm;
+                    *reinterpret_cast<f32x4*>(a.fuse.dlv + o) = gl;
+                }
+            }
+        };
+        switch (epi) {
+            case EPI_RELU: store_rows(std::integral_constant<int, EPI_RELU>{}); break;
+            case EPI_SIGMOID: store_rows(std::integral_constant<int, EPI_SIGMOID>{}); break;
+            case EPI_MASK: store_rows(std::integral_constant<int, EPI_MASK>{}); break;
+            case EPI_ACCUM: store_rows(std::integral_constant<int, EPI_ACCUM>{}); break;
+            case EPI_SIGMOID_BCE:
+                if constexpr (FUSE) store_rows(std::integral_constant<int, EPI_SIGMOID_BCE>{});
+                break;
+            case EPI_LATENT_BWD:
+                if constexpr (FUSE) store_rows(std::integral_constant<int, EPI_LATENT_BWD>{});
+                break;
+            default: store_rows(std::integral_constant<int, EPI_STORE>{}); break;
+        }
+    }
+    if (FUSE && epi == EPI_SIGMOID_BCE) {
+        // the wave's loss terms, lanes added in a fixed order; one slot per wave of every tile
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bce_sum += __shfl_xor(bce_sum, o);
+        if (lane == 0) a.fuse.bce_partial[(((long long)tm * a.tiles_n + tn) * GW + wave) * KG + kg] = bce_sum;
+    }
     }
     // Column sums of what this wave stored (its WTM rows x WTN columns), rows in a fixed order: a bias
     // gradient then needs no pass of its own over C, only the sum of these per-row-block partials.
@@ -1931,7 +2159,9 @@ int gemm_plan(const GemmDesc& d, GemmPlan& p)
         d.epi != EPI_POOL) {
         k.tail_ws = d.tail_ws;
         k.tail_counters = d.tail_counters;
-        k.tail_slots = tail_slots();
+        // resident blocks of the kernel that will run: two per CU, three of the fp16-plane kernel
+        k.tail_slots = (d.planes && d.planes_inv_a != nullptr) ? tail_slots() / 2 * 3 : tail_slots();
+        if (k.tail_slots > 1024) k.tail_slots = 1024;  // what gemm_tail_workspace() sizes the slabs and counters for
         grid += k.tail_slots;  // the split tail adds fewer than tail_slots blocks
     }
     if (grid > 0x7fffffffLL) return set_error(GTG_ERR_INVALID, "gemm: grid too large");
