@@ -692,6 +692,10 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         constexpr int PPW = PS::PIECES / 4;  // pieces (1 KB wave instructions) per wave and stage
         static_assert(PPW * 4 == PS::PIECES, "a stage must split evenly over the four waves");
         static_assert(PS::STAGES == 3 || PS::STAGES == 4, "the waits below are written out for rings of three and four");
+        // (A ring of four 16 KB stages with the fragments of step kt + 1 read while the MFMAs of step kt run -- two
+        // register sets, a branch-free steady-state loop -- took the fp16-plane kernel from 95.6 to 93.0 us at two
+        // blocks per CU; three blocks per CU on a ring of three do better, 87.5 us, and gain nothing from that
+        // double buffering (88.9 us), so the loop reads the stage it multiplies.)
         char* const lds = reinterpret_cast<char*>(smem);
         // this wave's pieces: piece q < NPL BM/32 is plane q / (BM/32), row block q % (BM/32) of A; the rest B alike.
         // Lane l fetches 16 bytes: row (l >> 1) of the block, k half (l & 1).  Rows past the operand's last one are
@@ -732,25 +736,34 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
 #pragma unroll
         for (int t = 0; t < PS::STAGES - 1; ++t)
             if (nk > t) issue(t);
-        bf16x8 fa[2][TM][NPL], fb[2][TN][NPL];
-        auto read_frags = [&](int kt, auto set_tag) {
-            constexpr int S = decltype(set_tag)::value;
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt was issued STAGES - 1 iterations ago; the only younger loads are those of the up to
+            // STAGES - 2 stages after it
+            const int younger = min(PS::STAGES - 2, nk - 1 - kt);
+            if (younger >= 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (younger == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // every wave's share of stage kt has landed, and every wave has finished reading stage kt - 1, whose
+            // buffer stage kt + STAGES - 1 now overwrites
+            __builtin_amdgcn_s_barrier();
+            if (kt + PS::STAGES - 1 < nk) issue(kt + PS::STAGES - 1);
             const char* stage = lds + (kt % PS::STAGES) * PS::STAGE_BYTES;
+            bf16x8 fa[TM][NPL], fb[TN][NPL];
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fa[S][i][pl] = __builtin_bit_cast(
+                    fa[i][pl] = __builtin_bit_cast(
                         bf16x8, *reinterpret_cast<const u32x4*>(stage + pl * PS::PLANE_A + (wm + 32 * i + r) * PS::ROWB + h * 16));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    fb[S][j][pl] = __builtin_bit_cast(
+                    fb[j][pl] = __builtin_bit_cast(
                         bf16x8, *reinterpret_cast<const u32x4*>(stage + NPL * PS::PLANE_A + pl * PS::PLANE_B +
                                                                 (wn + 32 * j + r) * PS::ROWB + h * 16));
             }
-        };
-        auto products = [&](auto set_tag) {
-            constexpr int S = decltype(set_tag)::value;
             // products of plane pairs (pa, pb) with pa + pb < NPL, the small ones first
 #pragma unroll
             for (int sum = NPL - 1; sum >= 0; --sum)
@@ -760,73 +773,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = mfma_16bit<NPL == 2>(fa[S][i][pa], fb[S][j][sum - pa], acc[i][j]);
-        };
-        // wait until this wave's share of stage `kt` has landed, the last stage issued so far being `issued`
-        // (the loads of the stages after kt are the only younger ones)
-        auto wait_stage = [&](int kt, int issued) {
-            const int younger = min(issued, nk - 1) - kt;
-            if (younger >= 2)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-            else if (younger == 1)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        typedef std::integral_constant<int, 0> Set0;
-        typedef std::integral_constant<int, 1> Set1;
-        if constexpr (PS::STAGES >= 4) {
-            // The fragments of k step kt + 1 are read from LDS while the MFMAs of step kt run (two register sets;
-            // the loop is unrolled by two so that they are fixed registers): a wave no longer stands still for the
-            // LDS latency of its reads in every step.  Stage kt + 1 must then be complete one step before its
-            // products need it: the loads run STAGES - 2 steps ahead of the reads (a ring of three would leave one).
-            auto step = [&](int kt, auto cur_tag, auto nxt_tag) {
-                if (kt + 1 < nk) {
-                    wait_stage(kt + 1, kt + PS::STAGES - 2);
-                    // every wave's share of stage kt + 1 has landed; every wave has consumed its fragments of stage
-                    // kt - 1 (its products of step kt - 1 are issued), whose buffer stage kt + STAGES - 1 overwrites
-                    __builtin_amdgcn_s_barrier();
-                    if (kt + PS::STAGES - 1 < nk) issue(kt + PS::STAGES - 1);
-                    read_frags(kt + 1, nxt_tag);
-                }
-                products(cur_tag);
-            };
-            // the same step where every condition above holds (kt + STAGES - 1 < nk), without a branch: in a
-            // straight-line loop body the compiler counts the outstanding LDS reads (the MFMAs of set `cur` wait
-            // for all but the eight reads of set `nxt` just issued) instead of draining them
-            auto steady_step = [&](int kt, auto cur_tag, auto nxt_tag) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PS::STAGES - 3) * PPW) : "memory");
-                __builtin_amdgcn_s_barrier();
-                issue(kt + PS::STAGES - 1);
-                read_frags(kt + 1, nxt_tag);
-                products(cur_tag);
-            };
-            if (nk > 0) {
-                wait_stage(0, PS::STAGES - 2);
-                __builtin_amdgcn_s_barrier();
-                read_frags(0, Set0{});
-            }
-            int kt = 0;
-            for (; kt + PS::STAGES < nk; kt += 2) {
-                steady_step(kt, Set0{}, Set1{});
-                steady_step(kt + 1, Set1{}, Set0{});
-            }
-            for (; kt < nk; kt += 2) {
-                step(kt, Set0{}, Set1{});
-                if (kt + 1 < nk) step(kt + 1, Set1{}, Set0{});
-            }
-        } else {
-            for (int kt = 0; kt < nk; ++kt) {
-                // stage kt was issued STAGES - 1 iterations ago; the only younger loads are those of the up to
-                // STAGES - 2 stages after it
-                wait_stage(kt, kt + PS::STAGES - 2);
-                // every wave's share of stage kt has landed, and every wave has finished reading stage kt - 1,
-                // whose buffer stage kt + STAGES - 1 now overwrites
-                __builtin_amdgcn_s_barrier();
-                if (kt + PS::STAGES - 1 < nk) issue(kt + PS::STAGES - 1);
-                read_frags(kt, Set0{});
-                products(Set0{});
-            }
+                            acc[i][j] = mfma_16bit<NPL == 2>(fa[i][pa], fb[j][sum - pa], acc[i][j]);
         }
         __syncthreads();  // the epilogue reuses the stages
     } else if constexpr (PREC == 0 && KG > 1 && GW == 1) {
