@@ -938,7 +938,12 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
         // run a copy of the loop without a single guard or branch in the step, so that the compiler can count
         // the outstanding loads instead of draining them and can place the split arithmetic between the MFMAs.
         constexpr int PL = PREC;
-        constexpr int DEPTH = 3;  // deeper rings (4, 5) measured no faster
+        // Ring depth: three tiles (deeper rings, 4 and 5, measured no faster); two for the fp16-split NT product on
+        // 128x128 tiles, whose 32 registers go to the fragments of the k step's second half instead (FRAGS_AHEAD in
+        // step(): requested up front, their LDS latency passes behind the first half's MFMAs and the staging
+        // arithmetic): forward product of the graph encoder 98.7 -> 97.2 us, the text branch's logits product
+        // 1.705 -> 1.644 ms, its LSTM input projection 0.209 -> 0.198 ms; the NN / TN forms measured no gain
+        constexpr int DEPTH = (PL == 2 && BM == 128 && AKC && BKC) ? 2 : 3;
         f32x4 ra[DEPTH][TA::NV], rb[DEPTH][TB::NV];
         const bool fast = m0 + BM <= Mr && n0 + BN <= a.N && (k_end - k_begin) % KS == 0 && nk > 0 && a.vecA && a.vecB;
         auto step = [&](auto fast_tag, int kt, auto slot_tag) {
@@ -946,15 +951,28 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
             constexpr int slot = decltype(slot_tag)::value;
             const float* cA = (kt & 1) ? sA1 : sA0;
             const float* cB = (kt & 1) ? sB1 : sB0;
+            constexpr bool FRAGS_AHEAD = (PL == 2 && KS == 32 && BM == 128 && AKC && BKC);
+            bf16x8 fa2[FRAGS_AHEAD ? TM : 1][PL], fb2[FRAGS_AHEAD ? TN : 1][PL];
+            if constexpr (FRAGS_AHEAD) {
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa2[i][pl] = TA::frag(cA, pl, wm + 32 * i, 1, r, h);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb2[j][pl] = TB::frag(cB, pl, wn + 32 * j, 1, r, h);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < KS / 16; ++g) {
                 bf16x8 fa[TM][PL], fb[TN][PL];
 #pragma unroll
                 for (int pl = 0; pl < PL; ++pl) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i][pl] = TA::frag(cA, pl, wm + 32 * i, g, r, h);
+                    for (int i = 0; i < TM; ++i)
+                        fa[i][pl] = (FRAGS_AHEAD && g == 1) ? fa2[FRAGS_AHEAD ? i : 0][pl] : TA::frag(cA, pl, wm + 32 * i, g, r, h);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j][pl] = TB::frag(cB, pl, wn + 32 * j, g, r, h);
+                    for (int j = 0; j < TN; ++j)
+                        fb[j][pl] = (FRAGS_AHEAD && g == 1) ? fb2[FRAGS_AHEAD ? j : 0][pl] : TB::frag(cB, pl, wn + 32 * j, g, r, h);
                 }
                 // products of plane pairs (pa, pb) with pa + pb < PL, the small ones first
 #pragma unroll
@@ -1029,7 +1047,8 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
             for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
                 if (kt0 < nk) step(fast_tag, kt0, std::integral_constant<int, 1 % DEPTH>());
                 if (kt0 + 1 < nk) step(fast_tag, kt0 + 1, std::integral_constant<int, 2 % DEPTH>());
-                if (kt0 + 2 < nk) step(fast_tag, kt0 + 2, std::integral_constant<int, 3 % DEPTH>());
+                if constexpr (DEPTH > 2)
+                    if (kt0 + 2 < nk) step(fast_tag, kt0 + 2, std::integral_constant<int, 3 % DEPTH>());
                 if constexpr (DEPTH > 3)
                     if (kt0 + 3 < nk) step(fast_tag, kt0 + 3, std::integral_constant<int, 4 % DEPTH>());
                 if constexpr (DEPTH > 4)
@@ -1038,7 +1057,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& a, float* const smem, con
                     if (kt0 + 5 < nk) step(fast_tag, kt0 + 5, std::integral_constant<int, 6 % DEPTH>());
             }
         };
-        static_assert(DEPTH >= 3 && DEPTH <= 6, "the step calls above are written out for rings of three to six");
+        static_assert(DEPTH >= 2 && DEPTH <= 6, "the step calls above are written out for rings of two to six");
         if (fast)
             run(std::true_type());
         else
