@@ -375,6 +375,66 @@ def gemm_planes_rows(Ap, Bp, rows_dev=None, bias=None, epilogue=0, aux=None, out
 
 
 # ---------------------------------------------------------------------------
+# weight gradients written where the optimiser reads them
+# ---------------------------------------------------------------------------
+def _grad_slot(weight, shape) -> Optional[torch.Tensor]:
+    """``weight.grad`` when the weight asks for its gradient to be STORED there: its ``grad_overwrite`` attribute
+    is true and ``.grad`` is already a dense contiguous fp32 GPU tensor of ``shape`` (JointTrainer's flat gradient
+    buffer).  The backward then writes the gradient into that tensor, replacing what it held -- right for a weight
+    that one call per backward pass uses, in a buffer nobody accumulates over passes --, returns None to autograd
+    (no temporary, no ``grad += new`` pass over the weight) and calls ``weight.grad_written()`` if that is set."""
+    if weight is None or not getattr(weight, "grad_overwrite", False):
+        return None
+    g = weight.grad
+    if g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == tuple(shape):
+        return g
+    return None
+
+
+def _grad_stored(*weights):
+    for w in weights:
+        cb = getattr(w, "grad_written", None)
+        if cb is not None:
+            cb()
+
+
+# ---------------------------------------------------------------------------
+# nn.Linear on the library's GEMM (the text branch's small layers)
+# ---------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y (rows, out) = x W^T + b (text_vae.py:41-42 hgen, z2emb): forward, dx = dy W and dW = dy^T x on the fp32
+    matrix pipe (the layers are a few hundred MFLOP: the matrix mode's split products would buy nothing); db, the
+    column sums of dy, is a torch reduction."""
+
+    @staticmethod
+    @_on_tensor_device
+    def forward(ctx, x, W, b):
+        x2, Wc, bc = _f32c(x.reshape(-1, x.shape[-1])), _f32c(W), _f32c(b)
+        if Wc.dim() != 2 or Wc.shape[1] != x2.shape[1] or (bc is not None and bc.numel() != Wc.shape[0]):
+            raise _lib.GtgError("linear: x (..., in), W (out, in), b (out)")
+        y = gemm(x2, Wc, True, True, bias=bc)
+        ctx.save_for_backward(x2, Wc)
+        ctx.lead = tuple(x.shape[:-1])
+        ctx.has_bias = b is not None
+        return y.view(ctx.lead + (Wc.shape[0],))
+
+    @staticmethod
+    @_on_tensor_device
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        dy2 = _f32c(dy.reshape(-1, W.shape[0]))
+        dx = gemm(dy2, W, True, False).view(ctx.lead + (W.shape[1],)) if ctx.needs_input_grad[0] else None
+        dW = gemm(dy2, x2, False, False) if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    """x W^T + b; see LinearFn."""
+    return LinearFn.apply(x, W, b)
+
+
+# ---------------------------------------------------------------------------
 # vocabulary projection + token cross-entropy (text decoder)
 # ---------------------------------------------------------------------------
 class ProjCEFn(torch.autograd.Function):
@@ -390,6 +450,7 @@ class ProjCEFn(torch.autograd.Function):
     def forward(ctx, H, W, b, targets, padidx, matrix_mode=None):
         L = _lib.lib()
         ctx.mode = mode = _lib.matrix_mode(matrix_mode)
+        ctx.w_param = W
         H, W, b = map(_f32c, (H, W, b))
         _lib.require_cuda(targets)
         targets = targets.contiguous().long().view(-1)
@@ -422,12 +483,15 @@ class ProjCEFn(torch.autograd.Function):
         gloss = _f32c(gloss).view(-1)
         dev = gloss.device
         dH = torch.empty((R, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
-        dW = torch.empty((V, K), dtype=torch.float32, device=dev)
+        slot = _grad_slot(ctx.w_param, (V, K))   # the weight's own .grad, if it asks for that (see _grad_slot)
+        dW = slot if slot is not None else torch.empty((V, K), dtype=torch.float32, device=dev)
         db = torch.empty((V,), dtype=torch.float32, device=dev) if has_bias else None
         ws = _ws(L.gtg_proj_ce_bwd_workspace_bytes(R, K, V), dev)
         check(L.gtg_proj_ce_bwd(ptr(W), ptr(gloss), ptr(rowmap), ptr(Hc), ptr(P), ldp, R, K, V, ptr(dH), ptr(dW),
                                 ptr(db), ctx.mode, ptr(ws), ws.numel(), stream_ptr()), "gtg_proj_ce_bwd")
-        return dH, dW, db, None, None, None
+        if slot is not None:
+            _grad_stored(ctx.w_param)
+        return dH, (None if slot is not None else dW), db, None, None, None
 
 
 def lstm_applies(T: int, B: int, I: int, H: int) -> bool:
@@ -445,6 +509,7 @@ class LSTMFn(torch.autograd.Function):
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, c0, reverse=False, matrix_mode=None):
         L = _lib.lib()
         ctx.mode = mode = _lib.matrix_mode(matrix_mode)
+        ctx.w_params = (w_ih, w_hh)
         x, w_ih, w_hh, b_ih, b_hh, h0, c0 = map(_f32c, (x, w_ih, w_hh, b_ih, b_hh, h0, c0))
         T, B, I = x.shape
         H = w_hh.shape[1]
@@ -479,8 +544,9 @@ class LSTMFn(torch.autograd.Function):
         dev = x.device
         need = ctx.needs_input_grad
         dx = torch.empty((T, B, I), dtype=torch.float32, device=dev) if need[0] else None
-        dw_ih = torch.empty((4 * H, I), dtype=torch.float32, device=dev)
-        dw_hh = torch.empty((4 * H, H), dtype=torch.float32, device=dev)
+        s_ih, s_hh = _grad_slot(ctx.w_params[0], (4 * H, I)), _grad_slot(ctx.w_params[1], (4 * H, H))
+        dw_ih = s_ih if s_ih is not None else torch.empty((4 * H, I), dtype=torch.float32, device=dev)
+        dw_hh = s_hh if s_hh is not None else torch.empty((4 * H, H), dtype=torch.float32, device=dev)
         db = torch.empty((4 * H,), dtype=torch.float32, device=dev)
         dh0 = torch.empty((B, H), dtype=torch.float32, device=dev) if (h0 is not None and need[5]) else None
         dc0 = torch.empty((B, H), dtype=torch.float32, device=dev) if (c0 is not None and need[6]) else None
@@ -488,7 +554,9 @@ class LSTMFn(torch.autograd.Function):
         check(L.gtg_lstm_bwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(h0), ptr(c0), ptr(hs), ptr(cs), ptr(gates), ptr(d_hs),
                              ptr(d_hT), ptr(d_cT), T, B, I, H, int(reverse), ptr(dx), ptr(dw_ih), ptr(dw_hh), ptr(db),
                              ptr(dh0), ptr(dc0), ctx.mode, ptr(ws), ws.numel(), stream_ptr()), "gtg_lstm_bwd")
-        return dx, dw_ih, dw_hh, db, db, dh0, dc0, None, None
+        _grad_stored(*(w for w, slot in zip(ctx.w_params, (s_ih, s_hh)) if slot is not None))
+        return (dx, None if s_ih is not None else dw_ih, None if s_hh is not None else dw_hh, db, db, dh0, dc0, None,
+                None)
 
 
 def lstm(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None, reverse=False, matrix_mode=None):

@@ -3,7 +3,7 @@ the optimiser and the data-parallel exchange of the graph-only fast path.
 
 The forward and backward run through the GTVAE module (HIP kernels for the graph half, the LSTM
 recurrences, the embedding lookup / dropout / word noise and the vocabulary projection + cross-entropy;
-autograd connects them, and the three small Linear layers hgen, z2emb, zg_* stay torch.nn.Linear).  What this class adds around the module:
+autograd connects them; the small Linear layers hgen and z2emb run on the library's GEMM as well).  What this class adds around the module:
 
 * every parameter and every gradient lives in ONE flat fp32 buffer each (the module's parameters are views
   into it), so the optimiser is a single ``gtg_adam_step`` launch over all 65 M+ parameters (train.py:290:
@@ -102,6 +102,14 @@ class JointTrainer:
         # EmbedDropoutFn); autograd then sees no gradient for it, so its hook below never fires and the bucket it
         # lives in (the last one) is launched after backward, when the scatter-adds have been enqueued
         named["text_vae.embed.weight"].grad_inplace = True
+        # the large weight gradients -- vocabulary projection, the LSTMs' W_ih / W_hh: 49 M of the text branch's
+        # 51 M weights -- are stored by their backward straight into their views of the flat buffer
+        # (functional._grad_slot): each is used by one call per pass and the buffer is cleared every step, so
+        # storing equals accumulating, without autograd's `grad += new` pass over each of them
+        self._stored = [k for k in named if k == "text_vae.proj.weight" or
+                        (k.startswith(("text_vae.E.weight_", "text_vae.G.weight_")))]
+        for k in self._stored:
+            named[k].grad_overwrite = True
         self.buckets = GradBuckets(self.flat_g, bounds, group)
         self.world = self.buckets.world
 
@@ -114,6 +122,8 @@ class JointTrainer:
                     self._bucket_of[k] = b
                     self._expected[b] += 1
                     named[k].register_post_accumulate_grad_hook(self._make_hook(b))
+                    if k in self._stored:   # autograd sees no gradient for it: its backward reports instead
+                        named[k].grad_written = (lambda h=self._make_hook(b): h(None))
         self._waiting = list(self._expected)
         self._next_bucket = 0
         self._reduce_now = False

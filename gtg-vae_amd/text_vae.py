@@ -120,13 +120,19 @@ class DAE(TextModel):
         """self.drop(x): the library's dropout on a GPU (mask regenerated in the backward, never stored)."""
         return Fn.dropout(x, self.drop.p, self.training) if x.is_cuda else self.drop(x)
 
+    @staticmethod
+    def _linear(mod, x):
+        """``mod(x)`` for an ``nn.Linear``: the library's GEMM on a GPU (functional.linear), the stock module for a
+        model left on the CPU."""
+        return Fn.linear(x, mod.weight, mod.bias) if x.is_cuda else mod(x)
+
     def encode(self, input):
         emb = self._embed(input)
         _, (ht, _) = self.run_lstm(self.E, emb, need_output=False)
-        return self.hgen(torch.cat([ht[-2], ht[-1]], 1))
+        return self._linear(self.hgen, torch.cat([ht[-2], ht[-1]], 1))
 
     def decode(self, z, input, hidden=None):
-        emb = self._embed(input, self.z2emb(z))
+        emb = self._embed(input, self._linear(self.z2emb, z))
         output, hidden = self.run_lstm(self.G, emb, hidden)
         output = self._drop(output)
         logits = self.proj(output.view(-1, output.size(-1)))
@@ -140,7 +146,7 @@ class DAE(TextModel):
         attribute if one was set, else the package default."""
         if matrix_mode is None:
             matrix_mode = getattr(self, "matrix_mode", None)
-        emb = self._embed(input, self.z2emb(z))
+        emb = self._embed(input, self._linear(self.z2emb, z))
         output, hidden = self.run_lstm(self.G, emb, hidden)
         output = self._drop(output)
         loss, pred = Fn.proj_ce(output.reshape(-1, output.size(-1)), self.proj.weight, self.proj.bias,

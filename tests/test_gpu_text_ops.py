@@ -178,3 +178,72 @@ def test_embed_flags_an_id_outside_the_table():
         assert Fn.embed_dropout(torch.tensor([[1, 9]], device="cuda"), w).shape == (1, 2, 8)
     finally:
         Fn.EmbedDropoutFn.check_ids = False
+
+
+@pytest.mark.parametrize("lead,I,O,bias", [((256,), 2048, 256, True), ((256,), 256, 512, True), ((3, 5), 12, 7, False),
+                                          ((1,), 4, 4, True)])
+def test_linear_on_the_library_gemm_matches_float64(lead, I, O, bias):
+    """functional.linear (hgen, z2emb of text_vae.py:41-42): forward, dx, dW and db against float64, fp32
+    tolerance 2e-6 of the largest entry (products of 4 .. 2048 terms on the fp32 matrix pipe)."""
+    from gtg_vae_amd import functional as Fn
+
+    g = torch.Generator().manual_seed(I + O)
+    x = torch.randn(*lead, I, generator=g)
+    W = torch.randn(O, I, generator=g) / I ** 0.5
+    b = torch.randn(O, generator=g) if bias else None
+    dy = torch.randn(*lead, O, generator=g)
+    xc, Wc = x.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
+    bc = b.cuda().requires_grad_(True) if bias else None
+    y = Fn.linear(xc, Wc, bc)
+    assert y.shape == (*lead, O)
+    y.backward(dy.cuda())
+    x64, W64 = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True) if bias else None
+    ref = torch.nn.functional.linear(x64, W64, b64)
+    ref.backward(dy.double())
+    pairs = [(y, ref), (xc.grad, x64.grad), (Wc.grad, W64.grad)] + ([(bc.grad, b64.grad)] if bias else [])
+    for got, want in pairs:
+        err = (got.detach().double().cpu() - want.detach()).abs().max().item() / want.detach().abs().max().item()
+        assert err < 2e-6, err
+
+
+def test_weight_gradients_stored_into_their_flat_buffer_views_equal_the_returned_ones():
+    """Weights marked ``grad_overwrite`` whose .grad exists (JointTrainer's flat buffer): the vocabulary projection
+    and the LSTM store dW / dW_ih / dW_hh there -- bit-identical to the tensors they return to autograd otherwise,
+    whatever the slot held before --, autograd receives nothing for them, ``grad_written`` is called once per
+    weight, and the other gradients are unchanged."""
+    from gtg_vae_amd import functional as Fn
+
+    g = torch.Generator().manual_seed(9)
+    R, K, V, T, B, I, H = 70, 64, 300, 5, 14, 16, 64
+    Hm = torch.randn(R, K, generator=g).cuda()
+    tg = torch.randint(0, V, (R,), generator=g).cuda()
+    tg[::7] = 0
+    x = torch.randn(T, B, I, generator=g).cuda()
+    dhs = torch.randn(T, B, H, generator=g).cuda()
+
+    def params():
+        gg = torch.Generator().manual_seed(10)
+        mk = lambda *s: torch.nn.Parameter((torch.randn(*s, generator=gg) * 0.1).cuda())
+        return mk(V, K), mk(V), mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)
+
+    def run(ps):
+        W, b, w_ih, w_hh, b_ih, b_hh = ps
+        loss, _ = Fn.proj_ce(Hm, W, b, tg, 0, "f16x2")
+        hs, hn, cn = Fn.lstm(x, w_ih, w_hh, b_ih, b_hh, None, None, False, "f16x2")
+        (loss.sum() + (hs * dhs).sum() + hn.sum()).backward()
+
+    plain = params()
+    run(plain)
+    stored = params()
+    calls = []
+    for i in (0, 2, 3):
+        stored[i].grad = torch.full_like(stored[i], 123.0)      # stale contents: must be replaced, not added to
+        stored[i].grad_overwrite = True
+        stored[i].grad_written = (lambda i=i: calls.append(i))
+    slots = [stored[i].grad.data_ptr() for i in (0, 2, 3)]
+    run(stored)
+    assert sorted(calls) == [0, 2, 3]
+    assert [stored[i].grad.data_ptr() for i in (0, 2, 3)] == slots
+    for p, q in zip(plain, stored):
+        assert torch.equal(p.grad, q.grad)
