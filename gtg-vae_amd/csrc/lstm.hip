@@ -294,17 +294,19 @@ __global__ __launch_bounds__(256, 1) void lstm_step_kernel(const StepArgs a)
     }
 }
 
-// W_hh (4H, H) fp32 -> the two plane images the recurrence multiplies by.
-//   wf (forward):  B operand of h W_hh^T, rows permuted so that a 64-row tile holds the four gates of 16 units:
-//                  [pl][H/16][4H rows p][16], p = (u / 16) * 64 + g * 16 + u % 16  <-  W_hh[g H + u][k]
-//   wb (backward): B operand of dG W_hh (depth = the 4H gate rows in their own order):
+// W_hh (4H, H) fp32 -> one of the two plane images the recurrence multiplies by.
+//   forward (BACK false): B operand of h W_hh^T, rows permuted so that a 64-row tile holds the four gates of 16
+//                  units: [pl][H/16][4H rows p][16], p = (u / 16) * 64 + g * 16 + u % 16  <-  W_hh[g H + u][k]
+//   backward (BACK true): B operand of dG W_hh (depth = the 4H gate rows in their own order):
 //                  [pl][4H/16][H rows j][16]  <-  W_hh[q][j]
-// One output element per thread; either image may be null.  F16: two fp16 planes of W_hh times the power of two
-// its largest magnitude calls for (absmax: GEMM_ABSMAX_PARTS partial maxima of |W_hh|); inv_out[0] = its inverse.
-template <bool F16>
-__global__ __launch_bounds__(256) void lstm_wsplit_kernel(const float* __restrict__ w, int H, unsigned short* __restrict__ wf,
-                                                          unsigned short* __restrict__ wb, const float* __restrict__ absmax,
-                                                          float* __restrict__ inv_out)
+// A block walks tiles of 64 image rows x 16 depth values (one k block): thread t holds row t / 4 and the four
+// consecutive depth values (t % 4) * 4 .., so a wave stores 512 contiguous bytes per plane and reads 64-byte runs
+// of W_hh (forward: along a row of W_hh; backward: four rows, one element each, the neighbouring threads the
+// neighbouring columns).  H is a multiple of 64.  F16: two fp16 planes of W_hh times the power of two its largest
+// magnitude calls for (absmax: GEMM_ABSMAX_PARTS partial maxima of |W_hh|); inv_out[0] = its inverse.
+template <bool F16, bool BACK>
+__global__ __launch_bounds__(256) void lstm_wsplit_kernel(const float* __restrict__ w, int H, unsigned short* __restrict__ dst,
+                                                          const float* __restrict__ absmax, float* __restrict__ inv_out)
 {
     float scale = 1.f;
     if constexpr (F16) {
@@ -322,38 +324,51 @@ __global__ __launch_bounds__(256) void lstm_wsplit_kernel(const float* __restric
         if (blockIdx.x == 0 && threadIdx.x == 0) inv_out[0] = inverse;
     }
     const long long total = 4ll * H * H;
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool back = i >= total;
-    if (back) i -= total;
-    if (i >= total) return;
-    unsigned short* dst = back ? wb : wf;
-    if (dst == nullptr) return;
-    float x0;
-    if (!back) {
-        const long long kb = i / (64ll * H), p = (i >> 4) % (4ll * H);
-        const int kk = (int)(i & 15);
-        const long long nb = p >> 6;
-        const int g = (int)(p & 63) >> 4, u = (int)(p & 15);
-        x0 = w[((long long)g * H + nb * 16 + u) * H + kb * 16 + kk];
-    } else {
-        const long long kb = i / (16ll * H), j = (i >> 4) % H;
-        const int kk = (int)(i & 15);
-        x0 = w[(kb * 16 + kk) * H + j];
+    const int rl = threadIdx.x >> 2, kk0 = (threadIdx.x & 3) * 4;
+    // tiles: (k block, 64-row group); forward: H/16 k blocks x 4H/64 groups, backward: 4H/16 k blocks x H/64 groups
+    const int groups = BACK ? H / 64 : 4 * H / 64;
+    const int ntiles = (BACK ? 4 * H / 16 : H / 16) * groups;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int kb = tile / groups, grp = tile - kb * groups;
+        f32x4 x;
+        long long out;   // element index of the thread's four values in a plane
+        if constexpr (!BACK) {
+            // group = 16 hidden units nb, image rows p = g * 16 + u of it
+            const int g = rl >> 4, u = rl & 15;
+            x = *reinterpret_cast<const f32x4*>(w + ((long long)g * H + grp * 16 + u) * H + kb * 16 + kk0);
+            out = ((long long)kb * 4 * H + grp * 64 + rl) * 16 + kk0;
+        } else {
+            const int j = grp * 64 + rl;
+            const float* src = w + (long long)(kb * 16 + kk0) * H + j;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = src[(long long)e * H];
+            out = ((long long)kb * H + j) * 16 + kk0;
+        }
+        if constexpr (F16) {
+            u32x2 p0, p1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                unsigned short hs[2], ls[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float t = x[2 * q + e] * scale;
+                    const _Float16 hi = (_Float16)t, lo = (_Float16)(t - (float)hi);
+                    hs[e] = __builtin_bit_cast(unsigned short, hi);
+                    ls[e] = __builtin_bit_cast(unsigned short, lo);
+                }
+                p0[q] = (unsigned)hs[0] | ((unsigned)hs[1] << 16);
+                p1[q] = (unsigned)ls[0] | ((unsigned)ls[1] << 16);
+            }
+            *reinterpret_cast<u32x2*>(dst + out) = p0;
+            *reinterpret_cast<u32x2*>(dst + total + out) = p1;
+        } else {
+            u32x2 p0, p1, p2;
+            split4(x, p0, p1, p2);
+            *reinterpret_cast<u32x2*>(dst + out) = p0;
+            *reinterpret_cast<u32x2*>(dst + total + out) = p1;
+            *reinterpret_cast<u32x2*>(dst + 2 * total + out) = p2;
+        }
     }
-    if constexpr (F16) {
-        const float t = x0 * scale;
-        const _Float16 hi = (_Float16)t, lo = (_Float16)(t - (float)hi);
-        dst[i] = __builtin_bit_cast(unsigned short, hi);
-        dst[total + i] = __builtin_bit_cast(unsigned short, lo);
-        return;
-    }
-    const unsigned b0 = __float_as_uint(x0) & 0xffff0000u;
-    const float x1 = x0 - __uint_as_float(b0);
-    const unsigned b1 = __float_as_uint(x1) & 0xffff0000u;
-    const float x2 = x1 - __uint_as_float(b1);
-    dst[i] = (unsigned short)(b0 >> 16);
-    dst[total + i] = (unsigned short)(b1 >> 16);
-    dst[2 * total + i] = (unsigned short)(__float_as_uint(x2) >> 16);
 }
 
 // An initial hidden state (rows, cols <= 1024) as the first step's A operand in fp16 planes: one block per row,
@@ -539,6 +554,7 @@ struct Carve {
 };
 
 inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+inline size_t min2(size_t a, size_t b) { return a < b ? a : b; }
 
 // K slabs of the backward step product: enough (M / 64) x (H / 64) x Z blocks for a block per CU
 inline int bwd_slabs(int B, int H)
@@ -638,16 +654,14 @@ int lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* 
         hipLaunchKernelGGL(lstm_prepare_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b_ih, b_hh, 4 * H, w.bias,
                            h0_bf16, B, H, w.hp[0], plane_h);
         if (int rc = check_launch("lstm_prepare_kernel")) return rc;
-        const long long total = 4ll * H * H;
-        const dim3 wgrid((unsigned)((total + 255) / 256));
+        const dim3 wgrid((unsigned)min2((size_t)(H / 16) * (4 * H / 64), (size_t)4096));
         if (f16) {
             if (int rc = absmax_partials(w_hh, 4ll * H, H, H, w.absmax, s)) return rc;
-            hipLaunchKernelGGL(lstm_wsplit_kernel<true>, wgrid, dim3(256), 0, s, w_hh, H, w.wf, (unsigned short*)nullptr,
-                               w.absmax, w.w_inv);
+            hipLaunchKernelGGL((lstm_wsplit_kernel<true, false>), wgrid, dim3(256), 0, s, w_hh, H, w.wf, w.absmax, w.w_inv);
             if (h0) hipLaunchKernelGGL(lstm_h0_planes_f16_kernel, dim3(B), dim3(256), 0, s, h0, B, H, w.hp[0], plane_h, w.a_inv);
         } else {
-            hipLaunchKernelGGL(lstm_wsplit_kernel<false>, wgrid, dim3(256), 0, s, w_hh, H, w.wf, (unsigned short*)nullptr,
-                               (const float*)nullptr, (float*)nullptr);
+            hipLaunchKernelGGL((lstm_wsplit_kernel<false, false>), wgrid, dim3(256), 0, s, w_hh, H, w.wf, (const float*)nullptr,
+                               (float*)nullptr);
         }
         if (int rc = check_launch("lstm_wsplit_kernel")) return rc;
     }
@@ -703,14 +717,13 @@ int lstm_bwd(const float* x, const float* w_ih, const float* w_hh, const float* 
     const long long BH = (long long)B * H, total = 4ll * H * H;
     const bool f16 = lstm_f16(H);
     {
-        const dim3 wgrid((unsigned)((2 * total + 255) / 256));
+        const dim3 wgrid((unsigned)min2((size_t)(4 * H / 16) * (H / 64), (size_t)4096));
         if (f16) {
             if (int rc = absmax_partials(w_hh, 4ll * H, H, H, w.absmax, s)) return rc;
-            hipLaunchKernelGGL(lstm_wsplit_kernel<true>, wgrid, dim3(256), 0, s, w_hh, H, (unsigned short*)nullptr, w.wb,
-                               w.absmax, w.w_inv);
+            hipLaunchKernelGGL((lstm_wsplit_kernel<true, true>), wgrid, dim3(256), 0, s, w_hh, H, w.wb, w.absmax, w.w_inv);
         } else {
-            hipLaunchKernelGGL(lstm_wsplit_kernel<false>, wgrid, dim3(256), 0, s, w_hh, H, (unsigned short*)nullptr, w.wb,
-                               (const float*)nullptr, (float*)nullptr);
+            hipLaunchKernelGGL((lstm_wsplit_kernel<false, true>), wgrid, dim3(256), 0, s, w_hh, H, w.wb, (const float*)nullptr,
+                               (float*)nullptr);
         }
         if (int rc = check_launch("lstm_wsplit_kernel")) return rc;
         // (W_hh's maxima have been consumed: the slots now collect the gate gradients' maxima step by step)
