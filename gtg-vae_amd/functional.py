@@ -381,21 +381,15 @@ def _grad_slot(weight, shape) -> Optional[torch.Tensor]:
     """``weight.grad`` when the weight asks for its gradient to be STORED there: its ``grad_overwrite`` attribute
     is true and ``.grad`` is already a dense contiguous fp32 GPU tensor of ``shape`` (JointTrainer's flat gradient
     buffer).  The backward then writes the gradient into that tensor, replacing what it held -- right for a weight
-    that one call per backward pass uses, in a buffer nobody accumulates over passes --, returns None to autograd
-    (no temporary, no ``grad += new`` pass over the weight) and calls ``weight.grad_written()`` if that is set."""
+    that one call per backward pass uses, in a buffer nobody accumulates over passes -- and returns None to
+    autograd: no temporary, no ``grad += new`` pass over the weight.  (The weight's post-accumulate-grad hooks run
+    as usual: autograd calls them for a None gradient too, after the backward that stored it has returned.)"""
     if weight is None or not getattr(weight, "grad_overwrite", False):
         return None
     g = weight.grad
     if g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == tuple(shape):
         return g
     return None
-
-
-def _grad_stored(*weights):
-    for w in weights:
-        cb = getattr(w, "grad_written", None)
-        if cb is not None:
-            cb()
 
 
 # ---------------------------------------------------------------------------
@@ -489,8 +483,6 @@ class ProjCEFn(torch.autograd.Function):
         ws = _ws(L.gtg_proj_ce_bwd_workspace_bytes(R, K, V), dev)
         check(L.gtg_proj_ce_bwd(ptr(W), ptr(gloss), ptr(rowmap), ptr(Hc), ptr(P), ldp, R, K, V, ptr(dH), ptr(dW),
                                 ptr(db), ctx.mode, ptr(ws), ws.numel(), stream_ptr()), "gtg_proj_ce_bwd")
-        if slot is not None:
-            _grad_stored(ctx.w_param)
         return dH, (None if slot is not None else dW), db, None, None, None
 
 
@@ -554,7 +546,6 @@ class LSTMFn(torch.autograd.Function):
         check(L.gtg_lstm_bwd(ptr(x), ptr(w_ih), ptr(w_hh), ptr(h0), ptr(c0), ptr(hs), ptr(cs), ptr(gates), ptr(d_hs),
                              ptr(d_hT), ptr(d_cT), T, B, I, H, int(reverse), ptr(dx), ptr(dw_ih), ptr(dw_hh), ptr(db),
                              ptr(dh0), ptr(dc0), ctx.mode, ptr(ws), ws.numel(), stream_ptr()), "gtg_lstm_bwd")
-        _grad_stored(*(w for w, slot in zip(ctx.w_params, (s_ih, s_hh)) if slot is not None))
         return (dx, None if s_ih is not None else dw_ih, None if s_hh is not None else dw_hh, db, db, dh0, dc0, None,
                 None)
 

@@ -99,13 +99,14 @@ class JointTrainer:
                 self.g[k] = self.flat_g[o:o + n].view(shape)
                 named[k].grad = self.g[k]                 # autograd accumulates in place into the flat buffer
         # the embedding's gradient is scatter-added straight into its rows of the flat buffer (functional.
-        # EmbedDropoutFn); autograd then sees no gradient for it, so its hook below never fires and the bucket it
-        # lives in (the last one) is launched after backward, when the scatter-adds have been enqueued
+        # EmbedDropoutFn); autograd receives None for it, and still runs the parameter's post-accumulate hook
+        # below once every use of the table has been differentiated, i.e. when the scatter-adds have been enqueued
         named["text_vae.embed.weight"].grad_inplace = True
         # the large weight gradients -- vocabulary projection, the LSTMs' W_ih / W_hh: 49 M of the text branch's
         # 51 M weights -- are stored by their backward straight into their views of the flat buffer
         # (functional._grad_slot): each is used by one call per pass and the buffer is cleared every step, so
-        # storing equals accumulating, without autograd's `grad += new` pass over each of them
+        # storing equals accumulating, without autograd's `grad += new` pass over each of them (their
+        # post-accumulate hooks fire all the same, after the backward that stored them has returned)
         self._stored = [k for k in named if k == "text_vae.proj.weight" or
                         (k.startswith(("text_vae.E.weight_", "text_vae.G.weight_")))]
         for k in self._stored:
@@ -122,8 +123,6 @@ class JointTrainer:
                     self._bucket_of[k] = b
                     self._expected[b] += 1
                     named[k].register_post_accumulate_grad_hook(self._make_hook(b))
-                    if k in self._stored:   # autograd sees no gradient for it: its backward reports instead
-                        named[k].grad_written = (lambda h=self._make_hook(b): h(None))
         self._waiting = list(self._expected)
         self._next_bucket = 0
         self._reduce_now = False

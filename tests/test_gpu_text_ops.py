@@ -210,8 +210,8 @@ def test_linear_on_the_library_gemm_matches_float64(lead, I, O, bias):
 def test_weight_gradients_stored_into_their_flat_buffer_views_equal_the_returned_ones():
     """Weights marked ``grad_overwrite`` whose .grad exists (JointTrainer's flat buffer): the vocabulary projection
     and the LSTM store dW / dW_ih / dW_hh there -- bit-identical to the tensors they return to autograd otherwise,
-    whatever the slot held before --, autograd receives nothing for them, ``grad_written`` is called once per
-    weight, and the other gradients are unchanged."""
+    whatever the slot held before --, autograd receives nothing for them while their post-accumulate hooks still
+    run once each (data-parallel bucket counting relies on that), and the other gradients are unchanged."""
     from gtg_vae_amd import functional as Fn
 
     g = torch.Generator().manual_seed(9)
@@ -240,7 +240,7 @@ def test_weight_gradients_stored_into_their_flat_buffer_views_equal_the_returned
     for i in (0, 2, 3):
         stored[i].grad = torch.full_like(stored[i], 123.0)      # stale contents: must be replaced, not added to
         stored[i].grad_overwrite = True
-        stored[i].grad_written = (lambda i=i: calls.append(i))
+        stored[i].register_post_accumulate_grad_hook(lambda p, i=i: calls.append(i))
     slots = [stored[i].grad.data_ptr() for i in (0, 2, 3)]
     run(stored)
     assert sorted(calls) == [0, 2, 3]

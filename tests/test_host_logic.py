@@ -188,3 +188,30 @@ def test_packed_loader_batches_equal_the_per_graph_collate():
             got = list(DataLoader(data, B, N, shuffle=shuffle, seed=1))
             assert [g.num_graphs for g in got] == [B, B, B, 5]
             assert sorted(s for g in got for s in g.snts) == sorted(d.snts for d in data)
+
+
+def test_post_accumulate_hook_runs_for_a_gradient_the_backward_stored_itself():
+    """JointTrainer counts a bucket's finished gradients with post-accumulate-grad hooks, also for the weights
+    whose backward writes the gradient into .grad itself and returns None (embedding, vocabulary projection,
+    LSTM weights): autograd must call the hook for such a parameter too, once, after that backward returned."""
+    order = []
+
+    class StoresItsWeightGradient(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.w = w
+            return x * 2 + w.sum() * 0
+
+        @staticmethod
+        def backward(ctx, g):
+            ctx.w.grad.copy_(torch.full_like(ctx.w, 7.0))
+            order.append("backward")
+            return g * 2, None
+
+    w = torch.nn.Parameter(torch.ones(3))
+    x = torch.ones(3, requires_grad=True)
+    w.grad = torch.zeros(3)
+    w.register_post_accumulate_grad_hook(lambda p: order.append("hook w"))
+    StoresItsWeightGradient.apply(x, w).sum().backward()
+    assert order == ["backward", "hook w"]
+    assert torch.equal(w.grad, torch.full((3,), 7.0))
